@@ -1,0 +1,89 @@
+"""Seeded input generators shared by oracle/make_golden.py (which feeds them to
+the verbatim reference) and by tests/ (which feed them to the oracle and to the
+HIP path).  Test infrastructure.  Inputs are regenerated from seeds instead of
+being stored; each fixture carries an input checksum so RNG drift is detected
+instead of silently mis-compared."""
+import zlib
+
+import torch
+import torch.nn as nn
+
+
+def bf16r(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def checksum(*tensors) -> float:
+    return float(sum(t.detach().double().abs().sum() for t in tensors))
+
+
+ATTN_CASES = {
+    # name: (K, S, heads, d, schedule, t)
+    "d40_noinj": (3, 48, 2, 40, [], 500),
+    "d40_inj": (3, 48, 2, 40, [981, 961], 961),
+    "d40_t1000": (2, 40, 2, 40, [], 1000),
+    "d80_inj_tensor_sched": (2, 80, 2, 80, torch.tensor([981, 961]), 981),
+    "d64_K13_perframe": (13, 16, 2, 64, [], 1),
+    "d160_noinj": (2, 24, 1, 160, [981], 1),
+    "d64_ragged": (2, 72, 2, 64, [5], 5),
+}
+
+
+def attn_inputs(name):
+    """q, k, v [3K,S,D] fp32 holding bf16-representable values."""
+    K, S, h, d, _, _ = ATTN_CASES[name]
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000 + 17 * K + S)
+    D = h * d
+    return tuple(bf16r(torch.randn(3 * K, S, D, generator=g)) for _ in range(3))
+
+
+PROP_CASES = {
+    # name: (K, n, S, D, dtype of kf_attn_output / residual stream)
+    "n5_D320": (3, 5, 64, 320, torch.float32),
+    "n4_D80_bf16": (4, 4, 48, 80, torch.bfloat16),
+    "n2_D640": (2, 2, 40, 640, torch.float32),
+    "n8_D64_videolike": (3, 8, 56, 64, torch.bfloat16),
+}
+
+
+def prop_inputs(name):
+    """pivots [3,K,S,D] fp32, kf_attn_output [3K,S,D] (case dtype), and per chunk
+    the hidden states [3n,S,D] (case dtype; norm1 = exact upcast to fp32)."""
+    K, n, S, D, dt = PROP_CASES[name]
+    g = torch.Generator().manual_seed(1000 + K * 7 + n * 3 + S + D)
+    ln = nn.LayerNorm(D, elementwise_affine=False)
+    piv = bf16r(ln(torch.randn(3, K, S, D, generator=g)))
+    kf_out = bf16r(torch.randn(3 * K, S, D, generator=g)).to(dt)
+    hidden = []
+    for bi in range(K):
+        if "videolike" in name:
+            perm = torch.stack([torch.randperm(S, generator=g) for _ in range(n)])
+            src = piv[0, bi][perm.reshape(-1)].reshape(n, S, D) + 0.1 * torch.randn(n, S, D, generator=g)
+            tgt = torch.cat([src[None], torch.randn(2, n, S, D, generator=g)])
+        else:
+            tgt = ln(torch.randn(3, n, S, D, generator=g))
+        hidden.append(bf16r(tgt).reshape(3 * n, S, D).to(dt))
+    return piv, kf_out, hidden
+
+
+BLOCKS_CFG = dict(dims=(80, 160, 320), heads=2, cross_dim=32, K=3, n=2, S=(48, 32, 16, 8),
+                  seed=4321, schedule=[801, 781], conv_schedule=[801, 781, 761], n_chunks=3,
+                  timesteps=(801, 761, 1))
+
+
+def blocks_inputs(t):
+    """Per timestep: encoder states and, in block execution order, the hidden
+    inputs of the pivotal pass and of each chunk pass, plus the resnet inputs."""
+    cfg = BLOCKS_CFG
+    K, n = cfg["K"], cfg["n"]
+    g = torch.Generator().manual_seed(cfg["seed"] + t)
+    levels = [0, 0, 1, 1, 2, 2, 3, 2, 2, 2, 1, 1, 1, 0, 0, 0]
+
+    def hid(b):
+        return [torch.randn(3 * b, cfg["S"][l], cfg["dims"][min(l, 2)], generator=g) for l in levels]
+
+    return dict(enc=torch.randn(3 * K, 7, cfg["cross_dim"], generator=g),
+                enc_n=torch.randn(3 * n, 7, cfg["cross_dim"], generator=g),
+                pivotal=hid(K), chunks=[hid(n) for _ in range(cfg["n_chunks"])],
+                res_x=torch.randn(3 * n, cfg["dims"][2], 4, 4, generator=g),
+                res_temb=torch.randn(3 * n, 16, generator=g))

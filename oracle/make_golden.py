@@ -1,0 +1,189 @@
+"""Generate tests/golden/*.pt by EXECUTING THE VERBATIM REFERENCE (test infrastructure).
+
+Run in the build container, where /root/reference is mounted:
+
+    python oracle/make_golden.py
+
+The reference has no tests or golden vectors of its own, so the
+pin is the reference code itself: its hook closures are imported unmodified
+(oracle/ref_loader.py), driven through duck-typed diffusers stand-ins
+(tests/fake_diffusers.py) on seeded CPU fp32 inputs, and inputs + outputs are
+saved as small fixtures.  `/root/reference` does not exist on the GPU box, so
+these files are what travels.
+
+Fixtures
+  attn_core.pt   sa_forward closures (tokenflow_utils.py:114-199, 224-281) with
+                 to_q/to_k/to_v returning given tensors and to_out = identity.
+  propagate.pt   batch_cosine_sim + argmax (util.py:61-69; tokenflow_utils.py:335-343)
+                 and the gather/blend/residual of TokenFlowBlock.forward (361-397),
+                 obtained by running the real TokenFlowBlock with identity sub-modules.
+  blocks.pt      all hooks installed on a 16-block fake UNet
+                 (register_extended_attention_pnp, register_conv_injection,
+                 set_tokenflow, register_pivotal, register_batch_idx, register_time):
+                 per-block outputs of the pivotal pass and of chunks 0..2, and the
+                 patched resnet forward.  Module weights come from a seed; a
+                 checksum guards against RNG drift.
+"""
+import os
+import zlib
+import sys
+
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_loader  # noqa: E402
+from tests import fake_diffusers as fd  # noqa: E402
+from oracle.golden_util import digest  # noqa: E402
+from oracle import golden_cases as gc  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+class _Fixed(nn.Module):
+    """to_q / to_k / to_v stand-in that returns a clone of a fixed tensor."""
+
+    def __init__(self, t):
+        super().__init__()
+        self.t = t
+
+    def forward(self, x):
+        return self.t.clone()
+
+
+class CoreAttention(fd.Attention):
+    def __init__(self, q, k, v, heads):
+        D = q.shape[-1]
+        super().__init__(D, heads)
+        self.to_q, self.to_k, self.to_v = _Fixed(q), _Fixed(k), _Fixed(v)
+        self.to_out = nn.Identity()
+
+
+class _OneBlock(nn.Module):
+    def __init__(self, block):
+        super().__init__()
+        self.unet = nn.Module()
+        self.unet.blk = block
+        # register_extended_attention* also index up_blocks[1..3] (208-214): give
+        # them the same block so the re-wrap lands on it too.
+        holder = nn.Module()
+        holder.transformer_blocks = nn.ModuleList([block])
+        stage = nn.Module()
+        stage.attentions = nn.ModuleList([holder, holder, holder])
+        self.unet.up_blocks = nn.ModuleList([nn.Module(), stage, stage, stage])
+
+
+def gen_attn_core(tfu):
+    out = {}
+    for name, (K, S, h, d, sched, t) in gc.ATTN_CASES.items():
+        q, k, v = gc.attn_inputs(name)
+        D = h * d
+        blk = fd.BasicTransformerBlock(D, h)
+        blk.attn1 = CoreAttention(q, k, v, h)
+        tfu.register_extended_attention_pnp(_OneBlock(blk), sched)
+        blk.attn1.t = t
+        with torch.no_grad():
+            o_pnp = blk.attn1.forward(torch.zeros(3 * K, S, D))
+        # sdedit variant (224-281): never injects
+        blk2 = fd.BasicTransformerBlock(D, h)
+        blk2.attn1 = CoreAttention(q, k, v, h)
+        tfu.register_extended_attention(_OneBlock(blk2))
+        with torch.no_grad():
+            o_sde = blk2.attn1.forward(torch.zeros(3 * K, S, D))
+        out[name] = dict(input_checksum=gc.checksum(q, k, v), out_pnp=digest(o_pnp, 5),
+                         out_sdedit=digest(o_sde, 7))
+    return out
+
+
+class _ToFloat(nn.Module):
+    def forward(self, x):
+        return x.float()
+
+
+class _Zero(nn.Module):
+    def forward(self, x):
+        return torch.zeros_like(x)
+
+
+class _IdBlock(fd.BasicTransformerBlock):
+    """TokenFlowBlock host whose norm1 is an exact upcast (like an autocast
+    LayerNorm: fp32 out whatever the stream dtype) and whose tail (attn2, ff) is
+    switched off, so forward() returns attn_output + hidden_states only."""
+
+    def __init__(self, D):
+        nn.Module.__init__(self)
+        self.only_cross_attention = False
+        self.use_ada_layer_norm = False
+        self.use_ada_layer_norm_zero = False
+        self.norm1 = _ToFloat()
+        self.attn1 = None
+        self.attn2 = None
+        self.norm3 = _Zero()
+        self.ff = nn.Identity()
+
+
+def gen_propagate(tfu, util):
+    out = {}
+    for name, (K, n, S, D, dt) in gc.PROP_CASES.items():
+        piv, kf_out, hidden = gc.prop_inputs(name)
+        case = dict(input_checksum=gc.checksum(piv, kf_out, *hidden), chunks={})
+        blk = _IdBlock(D)
+        blk.__class__ = tfu.make_tokenflow_attention_block(blk.__class__)
+        blk.pivot_hidden_states = piv
+        blk.kf_attn_output = kf_out
+        blk.pivotal_pass = False
+        for bi in range(K):
+            blk.batch_idx = bi
+            with torch.no_grad():
+                res = blk.forward(hidden[bi].clone())      # = attn_output + hidden (+0 from ff(zero))
+                ids = [bi] if bi == 0 else [bi, bi - 1]
+                tgt = hidden[bi].float().view(3, n, S, D)[0]
+                sim = util.batch_cosine_sim(tgt.reshape(-1, D), piv[0][ids].reshape(-1, D))
+                idx = [c.argmax(-1) for c in sim.chunk(len(ids), dim=1)]
+            case["chunks"][bi] = dict(out=digest(res, 17), out_dtype=str(res.dtype),
+                                      idx=[i.to(torch.int16) for i in idx])
+        out[name] = case
+    return out
+
+
+def gen_blocks(tfu):
+    cfg = gc.BLOCKS_CFG
+    torch.manual_seed(cfg["seed"])
+    pipe = fd.FakePipeline(dims=cfg["dims"], heads=cfg["heads"], cross_dim=cfg["cross_dim"]).eval()
+    tfu.register_extended_attention_pnp(pipe, cfg["schedule"])
+    tfu.register_conv_injection(pipe, cfg["conv_schedule"])
+    tfu.set_tokenflow(pipe.unet)
+    out = dict(weights_checksum=gc.checksum(*pipe.parameters()), runs={})
+    blocks = [b for _, b in pipe.unet.transformer_blocks_in_order()]
+    for t in cfg["timesteps"]:     # qk+conv inject / conv only / none
+        tfu.register_time(pipe, t)
+        inp = gc.blocks_inputs(t)
+        run = dict(input_checksum=gc.checksum(*inp["pivotal"], *sum(inp["chunks"], [])), pivotal=[], chunks=[])
+        with torch.no_grad():
+            tfu.register_pivotal(pipe, True)
+            for blk, x in zip(blocks, inp["pivotal"]):
+                run["pivotal"].append(digest(blk(x, encoder_hidden_states=inp["enc"]), 61))
+            tfu.register_pivotal(pipe, False)
+            for c in range(cfg["n_chunks"]):
+                tfu.register_batch_idx(pipe, c)
+                run["chunks"].append([digest(blk(x, encoder_hidden_states=inp["enc_n"]), 61)
+                                      for blk, x in zip(blocks, inp["chunks"][c])])
+            run["resnet"] = digest(pipe.unet.up_blocks[1].resnets[1](inp["res_x"], inp["res_temb"]), 3)
+        out["runs"][t] = run
+    return out
+
+
+def main():
+    tfu, util = ref_loader.load()
+    os.makedirs(GOLDEN, exist_ok=True)
+    torch.save(gen_attn_core(tfu), os.path.join(GOLDEN, "attn_core.pt"))
+    torch.save(gen_propagate(tfu, util), os.path.join(GOLDEN, "propagate.pt"))
+    torch.save(gen_blocks(tfu), os.path.join(GOLDEN, "blocks.pt"))
+    for f in sorted(os.listdir(GOLDEN)):
+        print(f, os.path.getsize(os.path.join(GOLDEN, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
