@@ -1,0 +1,130 @@
+/*
+ * tokenflow_hip.h  --  C ABI of libtokenflow_hip.so (MI355X / gfx950 only).
+ *
+ * The drop-in boundary for TokenFlow's per-step hot path.  The reference has no
+ * native code and no FFI: its "operator interface" for this path is a set of
+ * torch-op sequences inside Python hook closures.  Each entry point below
+ * replaces one such sequence; the file:line after "replaces" is into
+ * omerbt/TokenFlow (mounted at /root/reference in the build container).
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / STL types.
+ *   - every function returns int: 0 = ok, >0 = hipError_t of a failed launch,
+ *     <0 = argument error (TF_ERR_*); never throws, never allocates, never
+ *     synchronises, keeps no global mutable state (re-entrant per stream).
+ *   - pointers are DEVICE pointers (tensor.data_ptr()); the stream is a
+ *     hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     all launches are asynchronous on that stream.
+ *   - tensors are dense row-major unless a leading dimension is given.
+ *   - branch layout everywhere is the reference's [source | uncond | cond]
+ *     (tokenflow_utils.py:117,312  `n_frames = batch_size // 3`).
+ */
+#ifndef TOKENFLOW_HIP_H
+#define TOKENFLOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TF_ABI_VERSION 1
+
+/* element types */
+#define TF_BF16 0
+#define TF_F16 1
+#define TF_F32 2
+
+/* argument errors */
+#define TF_ERR_NULL (-1)
+#define TF_ERR_DTYPE (-2)
+#define TF_ERR_SHAPE (-3)
+#define TF_ERR_ALIGN (-4)
+#define TF_ERR_WORKSPACE (-5)
+
+int tf_abi_version(void);
+
+/* Thread-local description of the last non-zero return value on this thread. */
+const char* tf_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Extended attention  --  replaces the body of sa_forward.forward between the
+ * q/k/v projections and to_out: tokenflow_utils.py:124-197 (PnP variant) and
+ * 234-279 (SDEdit variant; call with inject = 0).
+ *
+ *   q, k, v : [3, K, S, H*Dh]  (token stride = ld elements, ld >= H*Dh)
+ *   out     : [3, K, S, H*Dh]  dense, same dtype
+ *   source branch: frame f attends to its own S keys (lines 173,177);
+ *   uncond / cond: frame f attends to all K*S keys of its branch (133-138,
+ *   174-179) -- the bank is read in place, never replicated.
+ *   inject != 0: uncond and cond use the SOURCE branch's q and k (124-130),
+ *   by pointer aliasing; q and k are not modified.
+ *   scale = attn.scale (Dh^-0.5).  Dh in {40, 64, 80, 160}; dtype bf16 or f16;
+ *   S, ld multiples of 8.  fp32 softmax / accumulation, online softmax over
+ *   64-key tiles, P rounded to the input dtype before P.V (as the reference's
+ *   autocast path does).
+ *
+ *   ws: scratch for the transposed V bank; size from tf_ext_attn_workspace_bytes.
+ * ------------------------------------------------------------------------ */
+size_t tf_ext_attn_workspace_bytes(int K, int S, int H, int Dh, int dtype);
+
+int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void* out,
+                    int K, int S, int H, int Dh, int64_t ld, float scale, int inject,
+                    int dtype, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Nearest-neighbour token search  --  replaces batch_cosine_sim + chunk + argmax:
+ * util.py:61-69 and tokenflow_utils.py:335-343.
+ *
+ * tf_pivot_inv_norm: once per pivotal pass and block, inv_norm[r] = 1/||piv[r]||_2
+ *   for the rows of the source-branch pivots `pivot_hidden_states[0]` viewed as
+ *   [rows = K*S, D] (util.py:67).
+ *
+ * tf_nn_search: for every target row t (norm_hidden_states[0] as [n_tgt = n*S, D],
+ *   tokenflow_utils.py:335) and every selected keyframe p < P (kf[p] indexes the
+ *   K keyframes; the reference order is [i, i-1], lines 331-333):
+ *       idx[p, t] = argmax_j  <tgt[t], piv[kf[p], j]> * inv_norm[kf[p]*S + j]
+ *   first maximal j wins (torch.argmax).  The 1/||tgt[t]|| factor of util.py:66
+ *   is a positive per-row constant and cannot change the argmax, so targets are
+ *   never normalised.  idx is int32 [P, n_tgt].  D multiple of 8; dtype bf16/f16.
+ * ------------------------------------------------------------------------ */
+int tf_pivot_inv_norm(const void* piv, float* inv_norm, int64_t rows, int D, int dtype,
+                      void* stream);
+
+int tf_nn_search(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx,
+                 int64_t n_tgt, int S, int D, int P, int kf0, int kf1, int dtype,
+                 void* stream);
+
+/* ------------------------------------------------------------------------
+ * Gather + blend + residual  --  replaces tokenflow_utils.py:362-397
+ * (propagation branch): advanced-index of the cached keyframe outputs, the
+ * int64 [3, n*S, D] index expansion + gather (372-373 / 390), the materialised
+ * fp32 weight tensor (375-385), the blend (388) and the residual add (396-397).
+ *
+ *   kf_out : [3, K, S, D]      cached attn1 output of the pivotal pass (`in_dtype`)
+ *   idx    : int32 [P, n*S]    from tf_nn_search (same indices for all 3 branches, 344-348)
+ *   w      : float [n]         w1 per frame of the chunk (only read when P == 2)
+ *   resid  : [3, n, S, D] or NULL (`res_dtype`)   hidden_states added at 396-397
+ *   out    : [3, n, S, D]      (`out_dtype`)
+ *   P == 2:  out = (w*a1 + (1-w)*a2) + resid   evaluated in fp32 with the
+ *            reference's operation order and no fused multiply-add, so an fp32
+ *            `out` is bit-identical to the reference's.
+ *   P == 1:  out = a1 + resid  (fp32 add, rounded to out_dtype).
+ * ------------------------------------------------------------------------ */
+int tf_gather_blend(const void* kf_out, const int32_t* idx, const float* w, const void* resid,
+                    void* out, int K, int n, int S, int D, int P, int kf0, int kf1,
+                    int in_dtype, int res_dtype, int out_dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * PnP feature injection  --  replaces tokenflow_utils.py:87-91:
+ *   x viewed as [3, elems_per_branch]:  x[1] = x[0];  x[2] = x[0]   (in place)
+ * elem_bytes = bytes per element; elems_per_branch*elem_bytes multiple of 16.
+ * ------------------------------------------------------------------------ */
+int tf_inject_copy(void* x, int64_t elems_per_branch, int elem_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOKENFLOW_HIP_H */

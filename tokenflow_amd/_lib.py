@@ -1,0 +1,57 @@
+"""ctypes binding of libtokenflow_hip.so (C ABI: include/tokenflow_hip.h)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtokenflow_hip.so")
+
+TF_BF16, TF_F16, TF_F32 = 0, 1, 2
+ABI_VERSION = 1
+
+_c = ctypes
+_SIGNATURES = {
+    "tf_abi_version": (_c.c_int, []),
+    "tf_last_error": (_c.c_char_p, []),
+    "tf_ext_attn_workspace_bytes": (_c.c_size_t, [_c.c_int] * 5),
+    "tf_ext_attn_fwd": (_c.c_int, [_c.c_void_p] * 4 + [_c.c_int] * 4 + [_c.c_int64, _c.c_float, _c.c_int, _c.c_int,
+                                   _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "tf_pivot_inv_norm": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int, _c.c_void_p]),
+    "tf_nn_search": (_c.c_int, [_c.c_void_p] * 4 + [_c.c_int64] + [_c.c_int] * 6 + [_c.c_void_p]),
+    "tf_gather_blend": (_c.c_int, [_c.c_void_p] * 5 + [_c.c_int] * 10 + [_c.c_void_p]),
+    "tf_inject_copy": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class TokenflowHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (idempotent).  torch must be imported first so that the
+    library's libamdhip64 dependency resolves to the runtime torch already mapped."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (maps libamdhip64 before dlopen)
+    if not os.path.isfile(LIB_PATH):
+        raise TokenflowHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C tokenflow_amd/csrc`.  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.tf_abi_version() != ABI_VERSION:
+        raise TokenflowHipError(f"ABI version {lib.tf_abi_version()} != {ABI_VERSION}: rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().tf_last_error().decode(errors="replace")
+        raise TokenflowHipError(f"{what} failed (rc={rc}): {msg}")

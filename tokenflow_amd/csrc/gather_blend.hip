@@ -1,0 +1,201 @@
+// Token gather + two-keyframe blend + residual add, and the PnP feature-injection copy.
+// Replaces tokenflow_utils.py:362-397 and 87-91 of omerbt/TokenFlow.
+//
+// HBM-bound: each output row (D elements, 640 B .. 2.5 KB) is a contiguous row of one
+// keyframe's cached attention output, so a row gather is naturally coalesced.  One
+// thread owns one 8-element piece of one token and loops the 3 branches, re-using the
+// token's two int32 indices and the frame's weight; 16-byte loads/stores; fp32 math
+// with the reference's operation order and NO fma contraction, so fp32 results are
+// bit-identical to torch's  w1*a1 + (1-w1)*a2  (+ hidden_states).
+#include "tf_common.h"
+
+// bit-exactness vs torch needs separately rounded multiplies and adds: no fma contraction here
+#pragma clang fp contract(off)
+
+namespace {
+
+template <typename T>
+struct Vec8 {  // 8 elements of T as raw 16-byte words
+    static constexpr int WORDS = sizeof(T) * 8 / 16;
+    u32x4 w[WORDS];
+};
+
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&f)[8]) {
+    if constexpr (sizeof(T) == 4) {
+        const u32x4 a = ld16(p), b = ld16(p + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[i] = __uint_as_float(a[i]);
+            f[4 + i] = __uint_as_float(b[i]);
+        }
+    } else {
+        typedef T v8 __attribute__((ext_vector_type(8)));
+        const v8 v = __builtin_bit_cast(v8, ld16(p));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float (&f)[8]) {
+    if constexpr (sizeof(T) == 4) {
+        u32x4 a, b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i] = __float_as_uint(f[i]);
+            b[i] = __float_as_uint(f[4 + i]);
+        }
+        st16(p, a);
+        st16(p + 4, b);
+    } else {
+        typedef T v8 __attribute__((ext_vector_type(8)));
+        v8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (T)f[i];  // round-to-nearest-even
+        st16(p, __builtin_bit_cast(u32x4, v));
+    }
+}
+
+struct NoRes {};
+
+template <typename TIn, typename TRes, typename TOut, int P>
+__global__ __launch_bounds__(256) void gather_blend_kernel(const TIn* __restrict__ kf_out,
+                                                           const int32_t* __restrict__ idx,
+                                                           const float* __restrict__ w, const TRes* __restrict__ resid,
+                                                           TOut* __restrict__ out, int K, int n, int S, int D, int kf0,
+                                                           int kf1) {
+    const int ppr = D >> 3;  // pieces per row
+    const int64_t nS = (int64_t)n * S;
+    const int64_t total = nS * ppr;
+    const int64_t branch_in = (int64_t)K * S * D;
+    const int64_t branch_out = nS * D;
+    const TIn* src1 = kf_out + (int64_t)kf0 * S * D;
+    const TIn* src2 = kf_out + (int64_t)kf1 * S * D;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+        const int64_t t = g / ppr;
+        const int c = (int)(g - t * ppr) * 8;
+        const int i1 = idx[t];
+        float w1 = 0.f, w2 = 0.f;
+        int i2 = 0;
+        if constexpr (P == 2) {
+            i2 = idx[nS + t];
+            w1 = w[(int)(t / S)];
+            w2 = __fsub_rn(1.0f, w1);
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            float a1[8], o[8];
+            load8(src1 + b * branch_in + (int64_t)i1 * D + c, a1);
+            if constexpr (P == 2) {
+                float a2[8];
+                load8(src2 + b * branch_in + (int64_t)i2 * D + c, a2);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = __fadd_rn(__fmul_rn(w1, a1[i]), __fmul_rn(w2, a2[i]));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = a1[i];
+            }
+            const int64_t off = b * branch_out + t * D + c;
+            if constexpr (!__is_same(TRes, NoRes)) {
+                float h[8];
+                load8(resid + off, h);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = __fadd_rn(o[i], h[i]);
+            }
+            store8(out + off, o);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void inject_copy_kernel(u32x4* __restrict__ x, int64_t pieces_per_branch) {
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < pieces_per_branch;
+         g += (int64_t)gridDim.x * 256) {
+        const u32x4 v = x[g];
+        x[pieces_per_branch + g] = v;
+        x[2 * pieces_per_branch + g] = v;
+    }
+}
+
+struct GbArgs {
+    const void* kf_out;
+    const int32_t* idx;
+    const float* w;
+    const void* resid;
+    void* out;
+    int K, n, S, D, P, kf0, kf1;
+    hipStream_t st;
+};
+
+template <typename TIn, typename TRes, typename TOut>
+void launch_gb(const GbArgs& a) {
+    const int64_t total = (int64_t)a.n * a.S * (a.D >> 3);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (a.P == 2)
+        hipLaunchKernelGGL((gather_blend_kernel<TIn, TRes, TOut, 2>), dim3((unsigned)blocks), dim3(256), 0, a.st,
+                           (const TIn*)a.kf_out, a.idx, a.w, (const TRes*)a.resid, (TOut*)a.out, a.K, a.n, a.S, a.D,
+                           a.kf0, a.kf1);
+    else
+        hipLaunchKernelGGL((gather_blend_kernel<TIn, TRes, TOut, 1>), dim3((unsigned)blocks), dim3(256), 0, a.st,
+                           (const TIn*)a.kf_out, a.idx, a.w, (const TRes*)a.resid, (TOut*)a.out, a.K, a.n, a.S, a.D,
+                           a.kf0, a.kf0);
+}
+
+template <typename TIn, typename TRes>
+void dispatch_out(const GbArgs& a, int out_dtype) {
+    switch (out_dtype) {
+        case TF_BF16: launch_gb<TIn, TRes, __bf16>(a); break;
+        case TF_F16: launch_gb<TIn, TRes, _Float16>(a); break;
+        default: launch_gb<TIn, TRes, float>(a); break;
+    }
+}
+
+template <typename TIn>
+void dispatch_res(const GbArgs& a, int res_dtype, int out_dtype) {
+    if (!a.resid) return dispatch_out<TIn, NoRes>(a, out_dtype);
+    switch (res_dtype) {
+        case TF_BF16: dispatch_out<TIn, __bf16>(a, out_dtype); break;
+        case TF_F16: dispatch_out<TIn, _Float16>(a, out_dtype); break;
+        default: dispatch_out<TIn, float>(a, out_dtype); break;
+    }
+}
+
+}  // namespace
+
+extern "C" int tf_gather_blend(const void* kf_out, const int32_t* idx, const float* w, const void* resid, void* out,
+                               int K, int n, int S, int D, int P, int kf0, int kf1, int in_dtype, int res_dtype,
+                               int out_dtype, void* stream) {
+    TF_ARG(kf_out && idx && out && (P == 1 || w), TF_ERR_NULL, "tf_gather_blend: null pointer");
+    auto okdt = [](int d) { return d == TF_BF16 || d == TF_F16 || d == TF_F32; };
+    TF_ARG(okdt(in_dtype) && okdt(out_dtype) && (!resid || okdt(res_dtype)), TF_ERR_DTYPE,
+           "tf_gather_blend: dtypes in=%d res=%d out=%d", in_dtype, res_dtype, out_dtype);
+    TF_ARG(K > 0 && n > 0 && S > 0 && D > 0 && D % 8 == 0 && (P == 1 || P == 2) && kf0 >= 0 && kf0 < K &&
+               (P == 1 || (kf1 >= 0 && kf1 < K)),
+           TF_ERR_SHAPE, "tf_gather_blend: K=%d n=%d S=%d D=%d P=%d kf=(%d,%d)", K, n, S, D, P, kf0, kf1);
+    TF_ARG(tf_aligned16(kf_out) && tf_aligned16(out) && tf_aligned16(resid), TF_ERR_ALIGN,
+           "tf_gather_blend: tensors not 16-byte aligned");
+    GbArgs a{kf_out, idx, w, resid, out, K, n, S, D, P, kf0, kf1, reinterpret_cast<hipStream_t>(stream)};
+    switch (in_dtype) {
+        case TF_BF16: dispatch_res<__bf16>(a, res_dtype, out_dtype); break;
+        case TF_F16: dispatch_res<_Float16>(a, res_dtype, out_dtype); break;
+        default: dispatch_res<float>(a, res_dtype, out_dtype); break;
+    }
+    TF_LAUNCH_CHECK("tf_gather_blend");
+    return 0;
+}
+
+extern "C" int tf_inject_copy(void* x, int64_t elems_per_branch, int elem_bytes, void* stream) {
+    TF_ARG(x, TF_ERR_NULL, "tf_inject_copy: null pointer");
+    TF_ARG(elems_per_branch > 0 && elem_bytes > 0 && (elems_per_branch * elem_bytes) % 16 == 0, TF_ERR_SHAPE,
+           "tf_inject_copy: elems_per_branch=%lld elem_bytes=%d (bytes per branch %% 16 == 0)",
+           (long long)elems_per_branch, elem_bytes);
+    TF_ARG(tf_aligned16(x), TF_ERR_ALIGN, "tf_inject_copy: x not 16-byte aligned");
+    const int64_t pieces = elems_per_branch * elem_bytes / 16;
+    int64_t blocks = (pieces + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(inject_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<u32x4*>(x), pieces);
+    TF_LAUNCH_CHECK("tf_inject_copy");
+    return 0;
+}

@@ -1,0 +1,284 @@
+// Nearest-neighbour token search for gfx950:
+//   idx[p, t] = argmax_j <tgt[t], piv[kf[p], j]> * inv_norm[kf[p], j]
+// replaces util.py:61-69 (batch_cosine_sim) + tokenflow_utils.py:335-343 (chunk + argmax)
+// of omerbt/TokenFlow.  The [n*S, P*S] similarity matrix never leaves registers.
+//
+// Structure: a GEMM with an argmax epilogue.  M = pivots (MFMA A operand, rows),
+// N = targets (B operand, columns), contraction over D.  With the 32x32 C/D map a
+// lane owns ONE target column and 16 pivot rows per tile, so the running
+// (max, argmax) over pivots is lane-local; lanes l and l+32 are merged once at the
+// end, then the two pivot-half waves through LDS.  A workgroup owns TN targets and
+// sweeps ALL S pivots of its keyframe, so there is no cross-workgroup merge.
+//   workgroup = 256 threads = 4 waves as 2 (pivot halves) x 2 (target halves)
+//   tile      = 128 pivots x TN targets x 64 (D chunk), TN = 64*WN... see below
+//   LDS       = double-buffered A/B chunk images, 128-B rows, 16-B slots XOR-swizzled
+//               with ((row >> 1) & 7) -> conflict-free ds_read_b128 fragment reads
+//   pipeline  = global->register prefetch of chunk i+1 issued before the MFMAs of
+//               chunk i, LDS write after them, one barrier per chunk.
+#include "tf_common.h"
+
+namespace {
+
+constexpr int TM = 128;  // pivots per tile
+constexpr int BK = 64;   // D chunk
+
+__device__ __forceinline__ int swz_off(int row, int piece) {  // byte offset in a [rows][64] 16-bit tile
+    return row * 128 + ((piece ^ ((row >> 1) & 7)) << 4);
+}
+
+// ---------------------------------------------------------------------------
+// inv_norm[r] = 1 / ||piv[r]||_2, one wave per row.
+template <typename T>
+__global__ __launch_bounds__(256) void pivot_inv_norm_kernel(const typename T::elem* __restrict__ piv,
+                                                             float* __restrict__ inv_norm, int64_t rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int pieces = D >> 3;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const typename T::elem* row = piv + r * D;
+        float s = 0.f;
+        for (int p = lane; p < pieces; p += 64) {
+            u32x4 raw = ld16(row + p * 8);
+            typename T::vec8 v = __builtin_bit_cast(typename T::vec8, raw);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float x = (float)v[i];
+                s = fmaf(x, x, s);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) inv_norm[r] = 1.0f / sqrtf(s);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// WN = 32-target sub-tiles per wave (1 or 2): workgroup covers TN = 64*WN targets.
+template <typename T, int WN>
+__global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* __restrict__ tgt,
+                                                        const typename T::elem* __restrict__ piv,
+                                                        const float* __restrict__ inv_norm,
+                                                        int32_t* __restrict__ idx_out, int64_t n_tgt, int S,
+                                                        int D, int kf0, int kf1) {
+    typedef typename T::vec8 vec8;
+    constexpr int TN = 64 * WN;
+    constexpr int A_BYTES = TM * 128;
+    constexpr int B_BYTES = TN * 128;
+    constexpr int NPA = TM * 8 / 256;  // 16-B pieces per thread, A chunk
+    constexpr int NPB = TN * 8 / 256;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    auto sA = [&](int b) { return smem + b * (A_BYTES + B_BYTES); };
+    auto sB = [&](int b) { return smem + b * (A_BYTES + B_BYTES) + A_BYTES; };
+    float* sInv = reinterpret_cast<float*>(smem + 2 * (A_BYTES + B_BYTES));  // [2][TM]
+    float* sBestV = sInv + 2 * TM;                                           // [2][TN]
+    int* sBestI = reinterpret_cast<int*>(sBestV + 2 * TN);                   // [2][TN]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1;  // pivot half  (rows wr*64 .. +63 of the tile)
+    const int wc = wave & 1;   // target half (cols wc*32*WN .. )
+    const int hi = lane >> 5;
+    const int l31 = lane & 31;
+
+    const int p = blockIdx.y;
+    const int kf = p == 0 ? kf0 : kf1;
+    const typename T::elem* pv = piv + (int64_t)kf * S * D;
+    const float* inv = inv_norm + (int64_t)kf * S;
+    const int64_t t0 = (int64_t)blockIdx.x * TN;
+
+    const int n_mt = (S + TM - 1) / TM;
+    const int n_kc = (D + BK - 1) / BK;
+    const int total = n_mt * n_kc;
+
+    // per-thread staging pieces: piece id = tid + 256*i -> row = id >> 3, col piece = id & 7
+    u32x4 ra[NPA], rb[NPB];
+    float rinv = 0.f;
+
+    auto stage_load = [&](int it) {
+        const int mt = it / n_kc, kc = it - mt * n_kc;
+        const int col0 = kc * BK;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const int id = tid + 256 * i;
+            const int r = id >> 3, pc = id & 7;
+            int row = mt * TM + r;
+            row = row < S ? row : S - 1;  // clamped duplicates can never win (see epilogue)
+            const int col = col0 + pc * 8;
+            ra[i] = col < D ? ld16(pv + (int64_t)row * D + col) : u32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            const int id = tid + 256 * i;
+            const int r = id >> 3, pc = id & 7;
+            int64_t row = t0 + r;
+            row = row < n_tgt ? row : n_tgt - 1;
+            const int col = col0 + pc * 8;
+            rb[i] = col < D ? ld16(tgt + row * D + col) : u32x4{0, 0, 0, 0};
+        }
+        if (kc == 0 && tid < TM) {
+            int row = mt * TM + tid;
+            row = row < S ? row : S - 1;
+            rinv = inv[row];
+        }
+    };
+    auto stage_write = [&](int it) {
+        const int mt = it / n_kc, kc = it - mt * n_kc;
+        const int b = it & 1;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const int id = tid + 256 * i;
+            st16(sA(b) + swz_off(id >> 3, id & 7), ra[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            const int id = tid + 256 * i;
+            st16(sB(b) + swz_off(id >> 3, id & 7), rb[i]);
+        }
+        if (kc == 0 && tid < TM) sInv[(mt & 1) * TM + tid] = rinv;
+    };
+
+    f32x16 acc[2][WN];
+    float best_v[WN];
+    int best_i[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        best_v[j] = -INFINITY;
+        best_i[j] = 0;
+    }
+
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+
+    for (int it = 0; it < total; ++it) {
+        const int mt = it / n_kc, kc = it - mt * n_kc;
+        const bool has_next = it + 1 < total;
+        if (has_next) stage_load(it + 1);
+        if (kc == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+        const unsigned char* a = sA(it & 1);
+        const unsigned char* b = sB(it & 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            vec8 fa[2], fb[WN];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                fa[i] = __builtin_bit_cast(vec8, ld16(a + swz_off(wr * 64 + i * 32 + l31, ks * 2 + hi)));
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                fb[j] = __builtin_bit_cast(vec8, ld16(b + swz_off((wc * WN + j) * 32 + l31, ks * 2 + hi)));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = T::mfma32(fa[i], fb[j], acc[i][j]);
+        }
+        if (kc == n_kc - 1) {
+            // argmax epilogue: rows visited in ascending order, strict '>' keeps the first maximum
+            const float* si = sInv + (mt & 1) * TM;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = wr * 64 + i * 32 + cd_row(r, hi);
+                    const float w = si[rl];
+                    const int gi = mt * TM + rl;
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) {
+                        const float sc = acc[i][j][r] * w;
+                        if (sc > best_v[j]) {
+                            best_v[j] = sc;
+                            best_i[j] = gi;
+                        }
+                    }
+                }
+            }
+        }
+        if (has_next) stage_write(it + 1);
+        __syncthreads();
+    }
+
+    // merge lane l with lane l+32 (interleaved row sets): tie -> smaller index
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const float ov = __shfl_xor(best_v[j], 32);
+        const int oi = __shfl_xor(best_i[j], 32);
+        if (ov > best_v[j] || (ov == best_v[j] && oi < best_i[j])) {
+            best_v[j] = ov;
+            best_i[j] = oi;
+        }
+        if (hi == 0) {
+            const int col = (wc * WN + j) * 32 + l31;
+            sBestV[wr * TN + col] = best_v[j];
+            sBestI[wr * TN + col] = best_i[j];
+        }
+    }
+    __syncthreads();
+    if (tid < TN) {
+        float v0 = sBestV[tid], v1 = sBestV[TN + tid];
+        int i0 = sBestI[tid], i1 = sBestI[TN + tid];
+        if (v1 > v0 || (v1 == v0 && i1 < i0)) i0 = i1;
+        i0 = i0 < S ? i0 : S - 1;  // a clamped duplicate of row S-1 maps back to S-1
+        const int64_t t = t0 + tid;
+        if (t < n_tgt) idx_out[(int64_t)p * n_tgt + t] = i0;
+    }
+}
+
+template <typename T, int WN>
+int launch_nn(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, int64_t n_tgt, int S, int D,
+              int P, int kf0, int kf1, hipStream_t st) {
+    constexpr int TN = 64 * WN;
+    const size_t lds = 2 * (TM * 128 + TN * 128) + 2 * TM * 4 + 2 * TN * 8;
+    dim3 grid((unsigned)((n_tgt + TN - 1) / TN), (unsigned)P);
+    auto kern = nn_search_kernel<T, WN>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, reinterpret_cast<const typename T::elem*>(tgt),
+                       reinterpret_cast<const typename T::elem*>(piv), inv_norm, idx, n_tgt, S, D, kf0, kf1);
+    TF_LAUNCH_CHECK("tf_nn_search");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int tf_pivot_inv_norm(const void* piv, float* inv_norm, int64_t rows, int D, int dtype, void* stream) {
+    TF_ARG(piv && inv_norm, TF_ERR_NULL, "tf_pivot_inv_norm: null pointer");
+    TF_ARG(dtype == TF_BF16 || dtype == TF_F16, TF_ERR_DTYPE, "tf_pivot_inv_norm: dtype %d (bf16/f16 only)", dtype);
+    TF_ARG(rows > 0 && D > 0 && D % 8 == 0, TF_ERR_SHAPE, "tf_pivot_inv_norm: rows=%lld D=%d (D %% 8 == 0)",
+           (long long)rows, D);
+    TF_ARG(tf_aligned16(piv), TF_ERR_ALIGN, "tf_pivot_inv_norm: piv not 16-byte aligned");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const unsigned grid = (unsigned)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
+    if (dtype == TF_BF16)
+        hipLaunchKernelGGL(pivot_inv_norm_kernel<BF16>, dim3(grid), dim3(256), 0, st,
+                           reinterpret_cast<const __bf16*>(piv), inv_norm, rows, D);
+    else
+        hipLaunchKernelGGL(pivot_inv_norm_kernel<F16>, dim3(grid), dim3(256), 0, st,
+                           reinterpret_cast<const _Float16*>(piv), inv_norm, rows, D);
+    TF_LAUNCH_CHECK("tf_pivot_inv_norm");
+    return 0;
+}
+
+extern "C" int tf_nn_search(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, int64_t n_tgt,
+                            int S, int D, int P, int kf0, int kf1, int dtype, void* stream) {
+    TF_ARG(tgt && piv && inv_norm && idx, TF_ERR_NULL, "tf_nn_search: null pointer");
+    TF_ARG(dtype == TF_BF16 || dtype == TF_F16, TF_ERR_DTYPE, "tf_nn_search: dtype %d (bf16/f16 only)", dtype);
+    TF_ARG(n_tgt > 0 && S > 0 && D > 0 && D % 8 == 0 && (P == 1 || P == 2) && kf0 >= 0 && (P == 1 || kf1 >= 0),
+           TF_ERR_SHAPE, "tf_nn_search: n_tgt=%lld S=%d D=%d P=%d kf=(%d,%d)", (long long)n_tgt, S, D, P, kf0, kf1);
+    TF_ARG(tf_aligned16(tgt) && tf_aligned16(piv), TF_ERR_ALIGN, "tf_nn_search: inputs not 16-byte aligned");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // 128-target panels when they still give >= 2 workgroups per CU, else 64-target panels
+    const bool wide = ((n_tgt + 127) / 128) * P >= 512;
+    if (dtype == TF_BF16)
+        return wide ? launch_nn<BF16, 2>(tgt, piv, inv_norm, idx, n_tgt, S, D, P, kf0, kf1, st)
+                    : launch_nn<BF16, 1>(tgt, piv, inv_norm, idx, n_tgt, S, D, P, kf0, kf1, st);
+    return wide ? launch_nn<F16, 2>(tgt, piv, inv_norm, idx, n_tgt, S, D, P, kf0, kf1, st)
+                : launch_nn<F16, 1>(tgt, piv, inv_norm, idx, n_tgt, S, D, P, kf0, kf1, st);
+}

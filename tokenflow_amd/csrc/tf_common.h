@@ -1,0 +1,68 @@
+// Shared device/host helpers for the gfx950 kernels of libtokenflow_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/tokenflow_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// ---- element traits: the two 16-bit MFMA input types of gfx950 -------------
+struct BF16 {
+    typedef __bf16 elem;
+    typedef __bf16 vec8 __attribute__((ext_vector_type(8)));
+    typedef __bf16 vec4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+struct F16 {
+    typedef _Float16 elem;
+    typedef _Float16 vec8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 vec4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+// 32x32x16 MFMA fragment conventions used everywhere in this library
+// (cdna_hip_programming.md §3):
+//   A (32 x 16): lane l holds row (l & 31), k = 8*(l >> 5) .. +7   (8 contiguous elements)
+//   B (16 x 32): lane l holds col (l & 31), k = 8*(l >> 5) .. +7
+//   C/D (32 x 32): lane l holds col (l & 31), rows (r & 3) + 8*(r >> 2) + 4*(l >> 5), r = 0..15
+// Only the C/D map is relied on for addressing; A and B always use the SAME
+// lane->k assignment, so a contraction is correct for any k order.
+__device__ __forceinline__ int cd_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+template <typename T>
+__device__ __forceinline__ float to_f32(T x) { return (float)x; }
+
+// ---- host-side error plumbing ------------------------------------------------
+void tf_set_error(const char* fmt, ...);
+
+#define TF_ARG(cond, code, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            tf_set_error(__VA_ARGS__);     \
+            return (code);                 \
+        }                                  \
+    } while (0)
+
+#define TF_LAUNCH_CHECK(name)                                                   \
+    do {                                                                        \
+        hipError_t e_ = hipGetLastError();                                      \
+        if (e_ != hipSuccess) {                                                 \
+            tf_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return (int)e_;                                                     \
+        }                                                                       \
+    } while (0)
+
+static inline bool tf_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int tf_elem_bytes(int dtype) { return dtype == TF_F32 ? 4 : 2; }

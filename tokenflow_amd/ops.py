@@ -1,0 +1,133 @@
+"""Torch-tensor wrappers over the C ABI.  PyTorch supplies device memory and the
+current HIP stream; all arithmetic happens in the HIP kernels.  No fallbacks."""
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+
+_DT = {torch.bfloat16: _lib.TF_BF16, torch.float16: _lib.TF_F16, torch.float32: _lib.TF_F32}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.TokenflowHipError(
+                "tokenflow_amd ops run on MI355X only: got a CPU tensor (there is no CPU fallback)")
+
+
+def compute_dtype(t: torch.Tensor) -> torch.dtype:
+    """16-bit MFMA input type used for a tensor of dtype t.dtype (fp32 inputs are rounded to bf16)."""
+    return t.dtype if t.dtype in (torch.bfloat16, torch.float16) else torch.bfloat16
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float,
+             inject: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Extended attention core (tokenflow_utils.py:124-197).  q,k,v: [3K,S,D] bf16/f16, last dim
+    contiguous, equal token stride.  Returns [3K,S,D] in the same dtype."""
+    _need_gpu(q, k, v)
+    lib = _lib.load()
+    B, S, D = q.shape
+    if B % 3 or D % heads:
+        raise ValueError(f"ext_attn: batch {B} must be 3*K and D {D} divisible by heads {heads}")
+    K, dh = B // 3, D // heads
+    dt = _DT.get(q.dtype)
+    if dt is None or dt == _lib.TF_F32 or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise TypeError(f"ext_attn: q/k/v must share dtype bf16 or f16, got {q.dtype},{k.dtype},{v.dtype}")
+
+    def rows(t):
+        if t.stride(-1) != 1 or t.stride(0) != S * t.stride(1):
+            t = t.contiguous()
+        return t
+    q, k, v = rows(q), rows(k), rows(v)
+    ld = q.stride(1)
+    if k.stride(1) != ld or v.stride(1) != ld:
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        ld = D
+    if out is None:
+        out = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
+    nbytes = lib.tf_ext_attn_workspace_bytes(K, S, heads, dh, dt)
+    ws = _workspace(nbytes, q.device)
+    _lib.check(lib.tf_ext_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), K, S, heads, dh,
+                                   ld, float(scale), int(bool(inject)), dt, ws.data_ptr(), ws.numel(), _stream()),
+               "tf_ext_attn_fwd")
+    return out
+
+
+def pivot_inv_norm(piv: torch.Tensor) -> torch.Tensor:
+    """1/||row|| for pivots [..., D] (bf16/f16, contiguous) -> fp32 [...]."""
+    _need_gpu(piv)
+    lib = _lib.load()
+    piv = piv.contiguous()
+    D = piv.shape[-1]
+    rows = piv.numel() // D
+    out = torch.empty(piv.shape[:-1], dtype=torch.float32, device=piv.device)
+    _lib.check(lib.tf_pivot_inv_norm(piv.data_ptr(), out.data_ptr(), rows, D, _DT[piv.dtype], _stream()),
+               "tf_pivot_inv_norm")
+    return out
+
+
+def nn_search(tgt: torch.Tensor, piv: torch.Tensor, inv_norm: torch.Tensor, kf_ids: Sequence[int]) -> torch.Tensor:
+    """tgt [n*S, D], piv [K, S, D] (same 16-bit dtype), inv_norm fp32 [K, S]; kf_ids = 1 or 2 keyframe
+    indices in the reference's order [i, i-1] (tokenflow_utils.py:331-333).  Returns int32 [P, n*S]."""
+    _need_gpu(tgt, piv, inv_norm)
+    lib = _lib.load()
+    tgt, piv = tgt.contiguous(), piv.contiguous()
+    K, S, D = piv.shape
+    n_tgt = tgt.shape[0]
+    P = len(kf_ids)
+    if tgt.dtype != piv.dtype or tgt.shape[1] != D or P not in (1, 2) or any(not 0 <= i < K for i in kf_ids):
+        raise ValueError("nn_search: bad arguments")
+    idx = torch.empty(P, n_tgt, dtype=torch.int32, device=tgt.device)
+    _lib.check(lib.tf_nn_search(tgt.data_ptr(), piv.data_ptr(), inv_norm.data_ptr(), idx.data_ptr(), n_tgt, S, D, P,
+                                int(kf_ids[0]), int(kf_ids[1]) if P == 2 else 0, _DT[tgt.dtype], _stream()),
+               "tf_nn_search")
+    return idx
+
+
+def gather_blend(kf_out: torch.Tensor, idx: torch.Tensor, w: Optional[torch.Tensor], kf_ids: Sequence[int],
+                 n: int, residual: Optional[torch.Tensor], out_dtype: torch.dtype) -> torch.Tensor:
+    """kf_out [3K,S,D]; idx int32 [P, n*S]; w fp32 [n] (P == 2); residual [3n,S,D] or None.
+    Returns [3n,S,D] of out_dtype (tokenflow_utils.py:362-397)."""
+    _need_gpu(kf_out, idx, w, residual)
+    lib = _lib.load()
+    kf_out = kf_out.contiguous()
+    BK, S, D = kf_out.shape
+    K = BK // 3
+    P = len(kf_ids)
+    if residual is not None:
+        residual = residual.contiguous()
+    out = torch.empty(3 * n, S, D, dtype=out_dtype, device=kf_out.device)
+    _lib.check(lib.tf_gather_blend(kf_out.data_ptr(), idx.data_ptr(), w.data_ptr() if w is not None else 0,
+                                   residual.data_ptr() if residual is not None else 0, out.data_ptr(),
+                                   K, n, S, D, P, int(kf_ids[0]), int(kf_ids[1]) if P == 2 else 0,
+                                   _DT[kf_out.dtype], _DT[residual.dtype] if residual is not None else 0,
+                                   _DT[out_dtype], _stream()), "tf_gather_blend")
+    return out
+
+
+def inject_copy_(x: torch.Tensor) -> torch.Tensor:
+    """In place: x[n:2n] = x[:n]; x[2n:] = x[:n] with n = len(x)//3 (tokenflow_utils.py:87-91)."""
+    _need_gpu(x)
+    lib = _lib.load()
+    if x.shape[0] % 3 or not x.is_contiguous():
+        raise ValueError("inject_copy_: need a contiguous tensor whose batch is a multiple of 3")
+    per_branch = x.numel() // 3
+    _lib.check(lib.tf_inject_copy(x.data_ptr(), per_branch, x.element_size(), _stream()), "tf_inject_copy")
+    return x
