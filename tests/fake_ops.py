@@ -1,0 +1,56 @@
+"""Oracle-backed stand-in for `tokenflow_amd.ops` (TEST INFRASTRUCTURE).
+
+Lets the host logic of tokenflow_amd/hooks.py and tokenflow_amd/sharded.py run on CPU
+tensors in `-m "not gpu"` tests: tests monkeypatch `hooks.ops` / `sharded.ops` with an
+instance of this class.  The product never imports it.
+
+round16=True mimics the precision contract of the HIP ops (inputs rounded to bf16, fp32
+arithmetic, attention output rounded to bf16) so a CPU run can be compared with a GPU run.
+"""
+import torch
+
+from oracle import tokenflow_oracle as orc
+
+
+class FakeOps:
+    def __init__(self, round16: bool = False):
+        self.round16 = round16
+        self.calls = []
+
+    def _r(self, t):
+        return t.to(torch.bfloat16).float() if self.round16 else t.float()
+
+    def compute_dtype(self, t):
+        return t.dtype
+
+    def ext_attn(self, q, k, v, heads, scale, inject, out=None):
+        self.calls.append(("ext_attn", tuple(q.shape), bool(inject)))
+        o = orc.ext_attn_core(self._r(q), self._r(k), self._r(v), heads, scale, inject)
+        return self._r(o).to(q.dtype)
+
+    def pivot_inv_norm(self, piv):
+        return 1.0 / self._r(piv).norm(dim=-1)
+
+    def nn_search(self, tgt, piv, inv_norm, kf_ids):
+        self.calls.append(("nn_search", tuple(tgt.shape), tuple(kf_ids)))
+        sim = orc.batch_cosine_sim(self._r(tgt), self._r(piv[list(kf_ids)]).reshape(-1, piv.shape[-1]))
+        return torch.stack([c.argmax(-1) for c in sim.chunk(len(kf_ids), dim=1)]).to(torch.int32)
+
+    def gather_blend(self, kf_out, idx, w, kf_ids, n, residual, out_dtype):
+        self.calls.append(("gather_blend", tuple(kf_out.shape), tuple(kf_ids)))
+        BK, S, D = kf_out.shape
+        sel = kf_out.view(3, BK // 3, S, D)
+        a1 = sel[:, kf_ids[0]][:, idx[0].long()].float()
+        if len(kf_ids) == 2:
+            a2 = sel[:, kf_ids[1]][:, idx[1].long()].float()
+            w1 = w.view(1, n, 1, 1)
+            o = (w1 * a1.view(3, n, S, D) + (1 - w1) * a2.view(3, n, S, D)).reshape(3 * n, S, D)
+        else:
+            o = a1.reshape(3 * n, S, D)
+        if residual is not None:
+            o = o + residual.float()
+        return o.to(out_dtype)
+
+    def inject_copy_(self, x):
+        self.calls.append(("inject_copy_", tuple(x.shape)))
+        return orc.conv_inject_(x)

@@ -1,0 +1,185 @@
+"""Host logic of the drop-in hook layer (tokenflow_utils.py / tokenflow_amd/hooks.py) on CPU:
+the HIP ops are replaced by the oracle-backed FakeOps, so what is tested is everything
+around the kernels -- installation, per-module state, schedules, keyframe order, dtype
+promotion -- against the verbatim reference's golden outputs."""
+import pytest
+import torch
+
+import tokenflow_utils as tfu
+from oracle import golden_cases as gc
+from oracle.golden_util import check
+from tests import fake_diffusers as fd
+from tests.fake_ops import FakeOps
+from tokenflow_amd import hooks
+
+
+@pytest.fixture
+def fake_ops(monkeypatch):
+    f = FakeOps()
+    monkeypatch.setattr(hooks, "ops", f)
+    return f
+
+
+def _pipe():
+    cfg = gc.BLOCKS_CFG
+    torch.manual_seed(cfg["seed"])
+    return fd.FakePipeline(dims=cfg["dims"], heads=cfg["heads"], cross_dim=cfg["cross_dim"]).eval()
+
+
+def test_api_surface_matches_reference():
+    # tokenflow_utils.py:7,13,20,43,49,106,216,296,432 + the run scripts' `from util import ...`
+    import inspect
+    import util
+    sigs = {
+        "register_pivotal": ["diffusion_model", "is_pivotal"], "register_batch_idx": ["diffusion_model", "batch_idx"],
+        "register_time": ["model", "t"], "load_source_latents_t": ["t", "latents_path"],
+        "register_conv_injection": ["model", "injection_schedule"],
+        "register_extended_attention_pnp": ["model", "injection_schedule"], "register_extended_attention": ["model"],
+        "make_tokenflow_attention_block": ["block_class"], "set_tokenflow": ["model"]}
+    for name, params in sigs.items():
+        assert list(inspect.signature(getattr(tfu, name)).parameters) == params, name
+    for name in ("save_video", "seed_everything", "isinstance_str", "batch_cosine_sim"):
+        assert callable(getattr(util, name))
+
+
+def test_blocks_match_reference_golden(fake_ops, golden_blocks):
+    cfg = gc.BLOCKS_CFG
+    pipe = _pipe()
+    assert gc.checksum(*pipe.parameters()) == golden_blocks["weights_checksum"], "RNG drift"
+    tfu.register_extended_attention_pnp(pipe, torch.tensor(cfg["schedule"]))     # tensor schedule, as the driver passes
+    tfu.register_conv_injection(pipe, torch.tensor(cfg["conv_schedule"]))
+    tfu.set_tokenflow(pipe.unet)
+    blocks = [b for _, b in pipe.unet.transformer_blocks_in_order()]
+    for t in cfg["timesteps"]:
+        tfu.register_time(pipe, t)
+        inp = gc.blocks_inputs(t)
+        run = golden_blocks["runs"][t]
+        fake_ops.calls.clear()
+        with torch.no_grad():
+            tfu.register_pivotal(pipe, True)
+            for i, (blk, x) in enumerate(zip(blocks, inp["pivotal"])):
+                check(blk(x, encoder_hidden_states=inp["enc"]), run["pivotal"][i], 3e-5, f"t{t}/pivotal/{i}")
+            tfu.register_pivotal(pipe, False)
+            for c in range(cfg["n_chunks"]):
+                tfu.register_batch_idx(pipe, c)
+                for i, (blk, x) in enumerate(zip(blocks, inp["chunks"][c])):
+                    check(blk(x, encoder_hidden_states=inp["enc_n"]), run["chunks"][c][i], 3e-5, f"t{t}/chunk{c}/{i}")
+            y = pipe.unet.up_blocks[1].resnets[1](inp["res_x"], inp["res_temb"])
+            check(y, run["resnet"], 1e-6, f"t{t}/resnet")
+        # injection fires on exactly the 8 decoder blocks and only for scheduled timesteps (206-214)
+        n_inj = sum(1 for c in fake_ops.calls if c[0] == "ext_attn" and c[2])
+        assert n_inj == (8 if t in cfg["schedule"] else 0)
+        assert sum(1 for c in fake_ops.calls if c[0] == "inject_copy_") == (1 if t in cfg["conv_schedule"] else 0)
+        # keyframe order [i, i-1] (331-333)
+        kfs = [c[2] for c in fake_ops.calls if c[0] == "nn_search"]
+        assert kfs[:16] == [(0,)] * 16 and kfs[16:32] == [(1, 0)] * 16 and kfs[32:48] == [(2, 1)] * 16
+
+
+def test_sdedit_variant_never_injects(fake_ops):
+    pipe = _pipe()
+    tfu.register_extended_attention(pipe)
+    tfu.set_tokenflow(pipe.unet)
+    tfu.register_time(pipe, 1000)              # t == 1000 forces injection only in the pnp variant
+    tfu.register_pivotal(pipe, True)
+    blk = pipe.unet.up_blocks[3].attentions[0].transformer_blocks[0]
+    with torch.no_grad():
+        blk(torch.randn(6, 16, 80), encoder_hidden_states=torch.randn(6, 7, 32))
+    assert [c for c in fake_ops.calls if c[0] == "ext_attn"] == [("ext_attn", (6, 16, 80), False)]
+
+
+def test_t_1000_forces_injection_everywhere(fake_ops):
+    pipe = _pipe()
+    tfu.register_extended_attention_pnp(pipe, [])
+    tfu.set_tokenflow(pipe.unet)
+    tfu.register_time(pipe, 1000)
+    tfu.register_pivotal(pipe, True)
+    blk = pipe.unet.down_blocks[0].attentions[0].transformer_blocks[0]    # not one of the 8 injected blocks
+    with torch.no_grad():
+        blk(torch.randn(6, 16, 80), encoder_hidden_states=torch.randn(6, 7, 32))
+    assert fake_ops.calls[0] == ("ext_attn", (6, 16, 80), True)
+
+
+def test_state_attributes_and_class_swap(fake_ops):
+    pipe = _pipe()
+    tfu.register_extended_attention_pnp(pipe, [5])
+    tfu.set_tokenflow(pipe.unet)
+    blk = pipe.unet.mid_block.attentions[0].transformer_blocks[0]
+    assert type(blk).__name__ == "TokenFlowBlock" and tfu.isinstance_str(blk, "BasicTransformerBlock")
+    assert blk.attn1.injection_schedule == [] and "forward" in blk.attn1.__dict__
+    assert pipe.unet.up_blocks[2].attentions[1].transformer_blocks[0].attn1.injection_schedule == [5]
+    tfu.register_time(pipe, 5)
+    tfu.register_pivotal(pipe, True)
+    tfu.register_batch_idx(pipe, 3)
+    assert blk.pivotal_pass is True and blk.batch_idx == 3 and blk.attn1.t == 5 and blk.attn2.t == 5
+    assert pipe.unet.up_blocks[1].resnets[1].t == 5                        # tokenflow_utils.py:21-22
+    with torch.no_grad():
+        x = torch.randn(6, 8, 320)
+        blk(x, encoder_hidden_states=torch.randn(6, 7, 32))
+    assert blk.pivot_hidden_states.shape == (3, 2, 8, 320) and blk.kf_attn_output.shape == (6, 8, 320)
+    assert blk.attn_output is blk.kf_attn_output
+
+
+def test_propagation_dtype_promotion(fake_ops):
+    """chunk 0 keeps the stream dtype, chunks >= 1 promote to fp32 (tokenflow_utils.py:385-390)."""
+    blk = fd.BasicTransformerBlock(80, 2).eval().to(torch.bfloat16)
+    holder = torch.nn.Module()
+    holder.blk = blk
+    tfu.set_tokenflow(holder)
+    blk.pivotal_pass = False
+    K, n, S, D = 2, 2, 8, 80
+    blk.pivot_hidden_states = torch.randn(3, K, S, D)
+    blk._tf_pivots = blk.pivot_hidden_states[0].contiguous()
+    blk._tf_pivot_inv_norm = 1.0 / blk._tf_pivots.norm(dim=-1)
+    blk.kf_attn_output = torch.randn(3 * K, S, D).bfloat16()
+    seen = {}
+    orig = fake_ops.gather_blend
+
+    def spy(*a):
+        seen["dtype"] = a[-1]
+        return orig(*a)
+    fake_ops.gather_blend = spy
+    enc = torch.randn(3 * n, 7, 32).bfloat16()
+    with torch.no_grad():
+        blk.batch_idx = 0
+        blk(torch.randn(3 * n, S, D).bfloat16(), encoder_hidden_states=enc)
+        assert seen["dtype"] == torch.bfloat16
+        blk.batch_idx = 1
+        with pytest.raises(RuntimeError):      # fp32 stream into bf16 weights: same failure mode as the reference
+            blk(torch.randn(3 * n, S, D).bfloat16(), encoder_hidden_states=enc)
+        assert seen["dtype"] == torch.float32
+
+
+def test_load_source_latents_cache(tmp_path):
+    x = torch.randn(4, 4, 8, 8)
+    torch.save(x, tmp_path / "noisy_latents_981.pt")
+    a = tfu.load_source_latents_t(981, str(tmp_path))
+    b = tfu.load_source_latents_t(981, str(tmp_path))
+    assert torch.equal(a, x) and a is b
+    with pytest.raises(AssertionError, match="Missing latents"):
+        tfu.load_source_latents_t(1, str(tmp_path))
+
+
+def test_ops_fail_loudly_on_cpu():
+    """No CPU fallback: the real ops refuse CPU tensors."""
+    from tokenflow_amd import ops
+    from tokenflow_amd._lib import TokenflowHipError
+    x = torch.zeros(3, 8, 80, dtype=torch.bfloat16)
+    with pytest.raises(TokenflowHipError, match="no CPU fallback"):
+        ops.ext_attn(x, x, x, 2, 1.0, False)
+    with pytest.raises(TokenflowHipError):
+        ops.inject_copy_(torch.zeros(3, 16))
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function declared in include/tokenflow_hip.h is exported by the built library."""
+    import os
+    import re
+    from tokenflow_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "tokenflow_hip.h")).read()
+    declared = set(re.findall(r"\b(tf_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.tf_abi_version() == 1

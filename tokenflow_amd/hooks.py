@@ -1,0 +1,339 @@
+"""The reference's hook API for the per-step hot path, on MI355X kernels.
+
+Same function names, signatures, installation style and per-module state as
+omerbt/TokenFlow `tokenflow_utils.py` (paths below are into that repository), so the
+reference's `run_tokenflow_pnp.py` / `run_tokenflow_sdedit.py` import this through the
+drop-in module `tokenflow_utils.py` at the repo root, unmodified.
+
+What differs from the reference is only *how* the tensors are computed:
+
+* `sa_forward.forward` (114-199 / 224-281): the bank replication, head permutes, per-head
+  bmm/softmax/bmm loops and re-layout are one fused HIP launch (`ops.ext_attn`); injection
+  (124-130) is pointer aliasing instead of four in-place slice copies.
+* `TokenFlowBlock.forward` propagation branch (329-397): cosine similarity + argmax is
+  `ops.nn_search` (the similarity matrix is never materialised), gather + blend + residual
+  is `ops.gather_blend`.
+* `conv_forward.forward` (86-91): the two slice copies are `ops.inject_copy_`.
+* `t in injection_schedule` on a device tensor (86,124) costs a host sync per call in the
+  reference; the schedule is converted to a Python set once at registration.
+* `register_pivotal` / `register_batch_idx` (7-17) walk `named_modules()` of the whole
+  pipeline on every call in the reference; the matching blocks are cached per model.
+* `load_source_latents_t` (43-47) re-reads the file from disk on every call in the
+  reference; files are cached by (path, mtime).
+
+There is no CPU / eager fallback: the ops raise on CPU tensors or when the HIP library is
+missing.
+"""
+import os
+from typing import Type
+
+import torch
+
+from . import ops
+
+__all__ = [
+    "register_pivotal", "register_batch_idx", "register_time", "load_source_latents_t",
+    "register_conv_injection", "register_extended_attention_pnp", "register_extended_attention",
+    "make_tokenflow_attention_block", "set_tokenflow", "isinstance_str", "batch_cosine_sim",
+]
+
+
+def isinstance_str(x: object, cls_name: str) -> bool:
+    """Class-*name* match over the MRO (util.py:46-58): lets the hooks patch diffusers
+    modules without importing diffusers."""
+    return any(c.__name__ == cls_name for c in type(x).__mro__)
+
+
+def batch_cosine_sim(x, y):
+    """Public export of util.py:61-69, kept for API compatibility.  The hooks do NOT call
+    it: the product path is ops.nn_search, which never materialises this matrix."""
+    if type(x) is list:
+        x = torch.cat(x, dim=0)
+    if type(y) is list:
+        y = torch.cat(y, dim=0)
+    return (x / x.norm(dim=-1, keepdim=True)) @ (y / y.norm(dim=-1, keepdim=True)).T
+
+
+# --------------------------------------------------------------------------- state setters
+def _tokenflow_blocks(model):
+    cache = model.__dict__.get("_tf_block_cache")
+    if cache is None:
+        cache = [m for _, m in model.named_modules() if isinstance_str(m, "BasicTransformerBlock")]
+        model.__dict__["_tf_block_cache"] = cache
+    return cache
+
+
+def register_pivotal(diffusion_model, is_pivotal):
+    """tokenflow_utils.py:7-11."""
+    for module in _tokenflow_blocks(diffusion_model):
+        setattr(module, "pivotal_pass", is_pivotal)
+
+
+def register_batch_idx(diffusion_model, batch_idx):
+    """tokenflow_utils.py:13-17."""
+    for module in _tokenflow_blocks(diffusion_model):
+        setattr(module, "batch_idx", batch_idx)
+
+
+_DOWN = {0: [0, 1], 1: [0, 1], 2: [0, 1]}
+_UP = {1: [0, 1, 2], 2: [0, 1, 2], 3: [0, 1, 2]}
+_INJECTED_UP = {1: [1, 2], 2: [0, 1, 2], 3: [0, 1, 2]}
+
+
+def register_time(model, t):
+    """tokenflow_utils.py:20-40: `t` on up_blocks[1].resnets[1] and on attn1/attn2 of the 16 blocks."""
+    unet = model.unet
+    setattr(unet.up_blocks[1].resnets[1], "t", t)
+    for res, blocks in _UP.items():
+        for b in blocks:
+            tb = unet.up_blocks[res].attentions[b].transformer_blocks[0]
+            setattr(tb.attn1, "t", t)
+            setattr(tb.attn2, "t", t)
+    for res, blocks in _DOWN.items():
+        for b in blocks:
+            tb = unet.down_blocks[res].attentions[b].transformer_blocks[0]
+            setattr(tb.attn1, "t", t)
+            setattr(tb.attn2, "t", t)
+    tb = unet.mid_block.attentions[0].transformer_blocks[0]
+    setattr(tb.attn1, "t", t)
+    setattr(tb.attn2, "t", t)
+
+
+_latents_cache = {}
+
+
+def load_source_latents_t(t, latents_path):
+    """tokenflow_utils.py:43-47, with an in-memory cache keyed by (path, mtime)."""
+    latents_t_path = os.path.join(latents_path, f"noisy_latents_{t}.pt")
+    assert os.path.exists(latents_t_path), f"Missing latents at t {t} path {latents_t_path}"
+    key = (latents_t_path, os.path.getmtime(latents_t_path))
+    hit = _latents_cache.get(key)
+    if hit is None:
+        hit = torch.load(latents_t_path)
+        _latents_cache[key] = hit
+    return hit
+
+
+# --------------------------------------------------------------------------- schedules
+def _schedule_set(schedule):
+    """One-time conversion so that `t in schedule` never syncs the device."""
+    if schedule is None:
+        return None
+    if isinstance(schedule, torch.Tensor):
+        return set(schedule.detach().cpu().reshape(-1).tolist())
+    return set(float(s) if isinstance(s, torch.Tensor) else s for s in schedule)
+
+
+def _injecting(module) -> bool:
+    """`schedule is not None and (t in schedule or t == 1000)` (tokenflow_utils.py:86,124)."""
+    sched = module.__dict__.get("_tf_schedule_set")
+    if module.injection_schedule is None or sched is None:
+        return False
+    t = module.t
+    if isinstance(t, torch.Tensor):
+        t = t.item()
+    return t in sched or t == 1000
+
+
+def _set_schedule(module, injection_schedule):
+    setattr(module, "injection_schedule", injection_schedule)
+    module.__dict__["_tf_schedule_set"] = _schedule_set(injection_schedule)
+
+
+# --------------------------------------------------------------------------- PnP feature injection
+def register_conv_injection(model, injection_schedule):
+    """tokenflow_utils.py:49-104: replaces `up_blocks[1].resnets[1].forward`."""
+
+    def conv_forward(self):
+        def forward(input_tensor, temb):
+            hidden_states = input_tensor
+            hidden_states = self.norm1(hidden_states)
+            hidden_states = self.nonlinearity(hidden_states)
+            if self.upsample is not None:
+                if hidden_states.shape[0] >= 64:
+                    input_tensor = input_tensor.contiguous()
+                    hidden_states = hidden_states.contiguous()
+                input_tensor = self.upsample(input_tensor)
+                hidden_states = self.upsample(hidden_states)
+            elif self.downsample is not None:
+                input_tensor = self.downsample(input_tensor)
+                hidden_states = self.downsample(hidden_states)
+            hidden_states = self.conv1(hidden_states)
+            if temb is not None:
+                temb = self.time_emb_proj(self.nonlinearity(temb))[:, :, None, None]
+            if temb is not None and self.time_embedding_norm == "default":
+                hidden_states = hidden_states + temb
+            hidden_states = self.norm2(hidden_states)
+            if temb is not None and self.time_embedding_norm == "scale_shift":
+                scale, shift = torch.chunk(temb, 2, dim=1)
+                hidden_states = hidden_states * (1 + scale) + shift
+            hidden_states = self.nonlinearity(hidden_states)
+            hidden_states = self.dropout(hidden_states)
+            hidden_states = self.conv2(hidden_states)
+            if _injecting(self):
+                # source activations over uncond and cond (86-91): one broadcast-copy launch
+                if not hidden_states.is_contiguous():
+                    hidden_states = hidden_states.contiguous()
+                ops.inject_copy_(hidden_states)
+            if self.conv_shortcut is not None:
+                input_tensor = self.conv_shortcut(input_tensor)
+            return (input_tensor + hidden_states) / self.output_scale_factor
+
+        return forward
+
+    conv_module = model.unet.up_blocks[1].resnets[1]
+    conv_module.forward = conv_forward(conv_module)
+    _set_schedule(conv_module, injection_schedule)
+
+
+# --------------------------------------------------------------------------- extended attention
+def _make_sa_forward(self, pnp: bool):
+    to_out = self.to_out
+    if type(to_out) is torch.nn.modules.container.ModuleList:
+        to_out = self.to_out[0]          # dropout to_out[1] skipped, as 108-112
+
+    def forward(x, encoder_hidden_states=None, attention_mask=None):
+        is_cross = encoder_hidden_states is not None
+        encoder_hidden_states = encoder_hidden_states if is_cross else x
+        q = self.to_q(x)
+        k = self.to_k(encoder_hidden_states)
+        v = self.to_v(encoder_hidden_states)
+        inject = pnp and _injecting(self)
+        cdt = ops.compute_dtype(q)
+        out = ops.ext_attn(q.to(cdt), k.to(cdt), v.to(cdt), self.heads, self.scale, inject)
+        return to_out(out.to(q.dtype))
+
+    return forward
+
+
+def register_extended_attention_pnp(model, injection_schedule):
+    """tokenflow_utils.py:106-214: every BasicTransformerBlock.attn1 gets the extended
+    attention with an empty schedule (203-206); the 8 decoder blocks
+    up_blocks[1].attentions[1,2], up_blocks[2,3].attentions[0..2] get the real one (208-214)."""
+    for _, module in model.unet.named_modules():
+        if isinstance_str(module, "BasicTransformerBlock"):
+            module.attn1.forward = _make_sa_forward(module.attn1, pnp=True)
+            _set_schedule(module.attn1, [])
+    for res, blocks in _INJECTED_UP.items():
+        for block in blocks:
+            module = model.unet.up_blocks[res].attentions[block].transformer_blocks[0].attn1
+            module.forward = _make_sa_forward(module, pnp=True)
+            _set_schedule(module, injection_schedule)
+
+
+def register_extended_attention(model):
+    """tokenflow_utils.py:216-294 (SDEdit driver): extended attention, never injects."""
+    for _, module in model.unet.named_modules():
+        if isinstance_str(module, "BasicTransformerBlock"):
+            module.attn1.forward = _make_sa_forward(module.attn1, pnp=False)
+    for res, blocks in _INJECTED_UP.items():
+        for block in blocks:
+            module = model.unet.up_blocks[res].attentions[block].transformer_blocks[0].attn1
+            module.forward = _make_sa_forward(module, pnp=False)
+
+
+# --------------------------------------------------------------------------- TokenFlow block
+_weights_cache = {}
+
+
+def _blend_weights(n: int, device) -> torch.Tensor:
+    """w1 of tokenflow_utils.py:375-383.  s - p1 = j - n//2 and s - p2 = j + n - n//2 do not
+    depend on the chunk index, so the n-vector is computed once per (n, device) with the
+    reference's own torch ops (on the host, so the value is the CPU reference's)."""
+    key = (n, str(device))
+    w = _weights_cache.get(key)
+    if w is None:
+        s = torch.arange(0, n)
+        d1 = torch.abs(s - n // 2)
+        d2 = torch.abs(s + n - n // 2)
+        w = torch.sigmoid(d2 / (d1 + d2)).to(device)
+        _weights_cache[key] = w
+    return w
+
+
+def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[torch.nn.Module]:
+    """tokenflow_utils.py:296-429."""
+
+    class TokenFlowBlock(block_class):
+
+        def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None,
+                    encoder_attention_mask=None, timestep=None, cross_attention_kwargs=None,
+                    class_labels=None) -> torch.Tensor:
+            batch_size, sequence_length, dim = hidden_states.shape
+            n_frames = batch_size // 3
+            hidden_states = hidden_states.view(3, n_frames, sequence_length, dim)
+
+            if self.use_ada_layer_norm:
+                norm_hidden_states = self.norm1(hidden_states, timestep)
+            elif self.use_ada_layer_norm_zero:
+                norm_hidden_states, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.norm1(
+                    hidden_states, timestep, class_labels, hidden_dtype=hidden_states.dtype)
+            else:
+                norm_hidden_states = self.norm1(hidden_states)
+            norm_hidden_states = norm_hidden_states.view(3, n_frames, sequence_length, dim)
+
+            cross_attention_kwargs = cross_attention_kwargs if cross_attention_kwargs is not None else {}
+            if self.pivotal_pass:
+                # 326-327 + 352-360: cache the normalised features and the attention output
+                self.pivot_hidden_states = norm_hidden_states
+                src = norm_hidden_states[0]
+                self._tf_pivots = src.to(ops.compute_dtype(src)).contiguous()       # [K,S,D] 16-bit
+                self._tf_pivot_inv_norm = ops.pivot_inv_norm(self._tf_pivots)       # [K,S] fp32
+                self.attn_output = self.attn1(
+                    norm_hidden_states.view(batch_size, sequence_length, dim),
+                    encoder_hidden_states=encoder_hidden_states if self.only_cross_attention else None,
+                    **cross_attention_kwargs)
+                self.kf_attn_output = self.attn_output
+                if self.use_ada_layer_norm_zero:
+                    self.attn_output = gate_msa.unsqueeze(1) * self.attn_output
+                attn_output = self.attn_output
+                hidden_states = hidden_states.reshape(batch_size, sequence_length, dim)
+                hidden_states = attn_output + hidden_states
+            else:
+                if self.use_ada_layer_norm_zero:
+                    raise NotImplementedError(
+                        "TokenFlow propagation with AdaLayerNormZero blocks is not supported on the HIP path "
+                        "(Stable Diffusion UNets do not use it)")
+                # 329-348: nearest neighbours of the SOURCE branch among keyframe i (and i-1)
+                batch_idxs = [self.batch_idx]
+                if self.batch_idx > 0:
+                    batch_idxs.append(self.batch_idx - 1)
+                tgt = norm_hidden_states[0].reshape(n_frames * sequence_length, dim).to(self._tf_pivots.dtype)
+                idx = ops.nn_search(tgt, self._tf_pivots, self._tf_pivot_inv_norm, batch_idxs)
+                # 361-397: gather (same indices for the 3 branches), blend, residual -- one launch.
+                # dtype follows torch promotion in the reference: the blend is fp32 (w1 is fp32, 385-388),
+                # chunk 0 keeps the cached dtype (390); then `attn_output + hidden_states` (397).
+                kf = self.kf_attn_output
+                blend_dtype = torch.float32 if len(batch_idxs) == 2 else kf.dtype
+                out_dtype = torch.promote_types(blend_dtype, hidden_states.dtype)
+                w = _blend_weights(n_frames, kf.device) if len(batch_idxs) == 2 else None
+                hidden_states = ops.gather_blend(kf, idx, w, batch_idxs, n_frames,
+                                                 hidden_states.reshape(batch_size, sequence_length, dim), out_dtype)
+
+            if self.attn2 is not None:
+                norm_hidden_states = (
+                    self.norm2(hidden_states, timestep) if self.use_ada_layer_norm else self.norm2(hidden_states))
+                attn_output = self.attn2(norm_hidden_states, encoder_hidden_states=encoder_hidden_states,
+                                         attention_mask=encoder_attention_mask, **cross_attention_kwargs)
+                hidden_states = attn_output + hidden_states
+
+            norm_hidden_states = self.norm3(hidden_states)
+            if self.use_ada_layer_norm_zero:
+                norm_hidden_states = norm_hidden_states * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
+            ff_output = self.ff(norm_hidden_states)
+            if self.use_ada_layer_norm_zero:
+                ff_output = gate_mlp.unsqueeze(1) * ff_output
+            return ff_output + hidden_states
+
+    return TokenFlowBlock
+
+
+def set_tokenflow(model: torch.nn.Module):
+    """tokenflow_utils.py:432-448: class-swap every BasicTransformerBlock in place."""
+    for _, module in model.named_modules():
+        if isinstance_str(module, "BasicTransformerBlock"):
+            module.__class__ = make_tokenflow_attention_block(module.__class__)
+            if not hasattr(module, "use_ada_layer_norm_zero"):     # older diffusers (444-446)
+                module.use_ada_layer_norm = False
+                module.use_ada_layer_norm_zero = False
+    return model
