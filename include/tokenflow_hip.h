@@ -54,8 +54,13 @@ const char* tf_last_error(void);
  * q/k/v projections and to_out: tokenflow_utils.py:124-197 (PnP variant) and
  * 234-279 (SDEdit variant; call with inject = 0).
  *
- *   q, k, v : [3, K, S, H*Dh]  (token stride = ld elements, ld >= H*Dh)
- *   out     : [3, K, S, H*Dh]  dense, same dtype
+ *   k, v    : [3, K, S, H*Dh]   the key/value bank of all K keyframes (token stride = ld
+ *                               elements, ld >= H*Dh)
+ *   q       : [3, Kq, S, H*Dh]  queries of keyframes q_frame0 .. q_frame0+Kq-1 (same ld).
+ *                               Single GPU: Kq = K, q_frame0 = 0 (q is the reference's q).
+ *                               Frame-sharded multi-GPU: a rank passes its own keyframes' q
+ *                               and the all-gathered bank.
+ *   out     : [3, Kq, S, H*Dh]  dense, same dtype
  *   source branch: frame f attends to its own S keys (lines 173,177);
  *   uncond / cond: frame f attends to all K*S keys of its branch (133-138,
  *   174-179) -- the bank is read in place, never replicated.
@@ -71,8 +76,8 @@ const char* tf_last_error(void);
 size_t tf_ext_attn_workspace_bytes(int K, int S, int H, int Dh, int dtype);
 
 int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void* out,
-                    int K, int S, int H, int Dh, int64_t ld, float scale, int inject,
-                    int dtype, void* ws, size_t ws_bytes, void* stream);
+                    int K, int Kq, int q_frame0, int S, int H, int Dh, int64_t ld, float scale,
+                    int inject, int dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Nearest-neighbour token search  --  replaces batch_cosine_sim + chunk + argmax:

@@ -23,9 +23,17 @@ class FakeOps:
     def compute_dtype(self, t):
         return t.dtype
 
-    def ext_attn(self, q, k, v, heads, scale, inject, out=None):
+    def ext_attn(self, q, k, v, heads, scale, inject, out=None, q_frame0=0):
         self.calls.append(("ext_attn", tuple(q.shape), bool(inject)))
-        o = orc.ext_attn_core(self._r(q), self._r(k), self._r(v), heads, scale, inject)
+        K, Kq = k.shape[0] // 3, q.shape[0] // 3
+        qf = self._r(q)
+        if Kq != K:      # queries of a frame subset: embed at their global positions, slice the result
+            full = torch.zeros(3, K, *q.shape[1:])
+            full[:, q_frame0:q_frame0 + Kq] = qf.view(3, Kq, *q.shape[1:])
+            qf = full.view(3 * K, *q.shape[1:])
+        o = orc.ext_attn_core(qf, self._r(k), self._r(v), heads, scale, inject)
+        if Kq != K:
+            o = o.view(3, K, *q.shape[1:])[:, q_frame0:q_frame0 + Kq].reshape(3 * Kq, *q.shape[1:])
         return self._r(o).to(q.dtype)
 
     def pivot_inv_norm(self, piv):

@@ -1,0 +1,81 @@
+"""Frame-sharded path on 2 CPU processes (gloo): the exchange logic of
+tokenflow_amd/sharded.py with the oracle-backed FakeOps standing in for the HIP ops.
+Sharded results must equal the single-process results bit for bit (work is partitioned,
+not re-associated)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import tokenflow_oracle as orc
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _data(K, n, S, h, d, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    D = h * d
+    q, k, v = (torch.randn(3 * K, S, D, generator=g) for _ in range(3))
+    piv = torch.randn(K, S, D, generator=g)
+    kf_out = torch.randn(3 * K, S, D, generator=g)
+    tgt = torch.randn(K, n * S, D, generator=g)            # per chunk
+    res = torch.randn(K, 3 * n, S, D, generator=g)
+    return q, k, v, piv, kf_out, tgt, res
+
+
+def _worker(rank, world, port, K, n, S, h, d, inject, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.fake_ops import FakeOps
+        from tokenflow_amd import sharded
+        fake = FakeOps()
+        sharded.ops = fake
+        q, k, v, piv, kf_out, tgt, res = _data(K, n, S, h, d)
+        D = h * d
+        # ---- single-process reference (same fake ops, full data)
+        full_attn = fake.ext_attn(q, k, v, h, d ** -0.5, inject)
+        inv = fake.pivot_inv_norm(piv)
+        w = orc.blend_weights(n, 1)
+        full_prop = []
+        for c in range(K):
+            ids = orc.keyframe_ids(c)
+            idx = fake.nn_search(tgt[c], piv, inv, ids)
+            dt = torch.float32
+            full_prop.append(fake.gather_blend(kf_out, idx, w if len(ids) == 2 else None, ids, n, res[c], dt))
+        # ---- sharded
+        sh = sharded.FrameShard(K)
+        Kl, f0 = sh.Kl, sh.kf0
+        loc = lambda t: t.view(3, K, S, D)[:, f0:f0 + Kl].reshape(3 * Kl, S, D)
+        out = sh.pivotal_attention(loc(q), loc(k), loc(v), h, d ** -0.5, inject)
+        ok = torch.equal(out, loc(full_attn))
+        piv_e, inv_e, kfo_e = sh.exchange_halo(piv[f0:f0 + Kl], inv[f0:f0 + Kl], loc(kf_out))
+        for j in range(Kl):
+            y = sh.propagate(j, tgt[f0 + j], res[f0 + j], piv_e, inv_e, kfo_e, w, n)
+            ok = ok and torch.equal(y, full_prop[f0 + j])
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("inject", [False, True])
+def test_sharded_equals_single_process(inject):
+    world, K, n, S, h, d = 2, 4, 2, 12, 2, 8
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, K, n, S, h, d, inject, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_uneven_shards_rejected():
+    from tokenflow_amd import sharded
+    sh = sharded.FrameShard(5)          # world 1: fine
+    assert sh.Kl == 5 and sh.kf0 == 0

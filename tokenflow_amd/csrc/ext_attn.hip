@@ -53,7 +53,7 @@ struct AttnParams {
     const void* k;
     const void* vt;
     void* out;
-    int K, S, H, Spad, nQT, inject;
+    int K, Kq, q_frame0, S, H, Spad, nQT, inject;  // K bank frames; queries = frames q_frame0 .. +Kq
     int64_t ld;
     float c;  // scale * log2(e)
 };
@@ -102,16 +102,16 @@ __global__ __launch_bounds__(256) void ext_attn_kernel(AttnParams p) {
     const int wave = tid >> 6;
     const int hi = lane >> 5;
     const int l31 = lane & 31;
-    const int K = p.K, S = p.S, H = p.H;
+    const int K = p.K, Kq = p.Kq, S = p.S, H = p.H;
 
     // ---- problem decode: bank problems (uncond, cond) first, then the short source ones
     const int h = blockIdx.x % H;
     int u = blockIdx.x / H;
-    const int nbank = 2 * K * p.nQT;
-    int b, f, qt;
+    const int nbank = 2 * Kq * p.nQT;
+    int b, f, qt;  // f = query frame, local index in [0, Kq)
     if (u < nbank) {
-        b = 1 + u / (K * p.nQT);
-        const int r = u % (K * p.nQT);
+        b = 1 + u / (Kq * p.nQT);
+        const int r = u % (Kq * p.nQT);
         f = r / p.nQT;
         qt = r - f * p.nQT;
     } else {
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void ext_attn_kernel(AttnParams p) {
         qt = u - f * p.nQT;
     }
     const int bq = (p.inject && b > 0) ? 0 : b;  // branch whose q and k are used (tokenflow_utils.py:124-130)
-    const int f_lo = b == 0 ? f : 0;
+    const int f_lo = b == 0 ? p.q_frame0 + f : 0;
     const int n_fr = b == 0 ? 1 : K;
     const int tpf = (S + 63) >> 6;  // 64-key tiles per frame
     const int ntiles = n_fr * tpf;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void ext_attn_kernel(AttnParams p) {
     const bool q_ok = q_row < S;
     vec8 qf[C::KS];
     {
-        const E* qp = qg + (((int64_t)bq * K + f) * S + (q_ok ? q_row : S - 1)) * p.ld + h * DH;
+        const E* qp = qg + (((int64_t)bq * Kq + f) * S + (q_ok ? q_row : S - 1)) * p.ld + h * DH;
 #pragma unroll
         for (int t = 0; t < C::KS; ++t) {
             const int col = 16 * t + 8 * hi;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void ext_attn_kernel(AttnParams p) {
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv_l = 1.0f / l_tot;
     if (q_ok) {
-        E* op = reinterpret_cast<E*>(p.out) + (((int64_t)b * K + f) * S + q_row) * ((int64_t)H * DH) + h * DH;
+        E* op = reinterpret_cast<E*>(p.out) + (((int64_t)b * Kq + f) * S + q_row) * ((int64_t)H * DH) + h * DH;
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
@@ -316,7 +316,7 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
     auto kern = ext_attn_kernel<T, DH>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)C::LDS_BYTES);
-    const unsigned grid = (unsigned)(3 * p.K * p.nQT * p.H);
+    const unsigned grid = (unsigned)(3 * p.Kq * p.nQT * p.H);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, st, p);
     TF_LAUNCH_CHECK("tf_ext_attn_fwd");
     return 0;
@@ -341,15 +341,17 @@ extern "C" size_t tf_ext_attn_workspace_bytes(int K, int S, int H, int Dh, int d
     return (size_t)3 * H * Dh * K * Spad * 2;
 }
 
-extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void* out, int K, int S, int H, int Dh,
-                               int64_t ld, float scale, int inject, int dtype, void* ws, size_t ws_bytes,
-                               void* stream) {
+extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void* out, int K, int Kq, int q_frame0,
+                               int S, int H, int Dh, int64_t ld, float scale, int inject, int dtype, void* ws,
+                               size_t ws_bytes, void* stream) {
     TF_ARG(q && k && v && out && ws, TF_ERR_NULL, "tf_ext_attn_fwd: null pointer");
     TF_ARG(dtype == TF_BF16 || dtype == TF_F16, TF_ERR_DTYPE, "tf_ext_attn_fwd: dtype %d (bf16/f16 only)", dtype);
     TF_ARG(Dh == 40 || Dh == 64 || Dh == 80 || Dh == 160, TF_ERR_SHAPE,
            "tf_ext_attn_fwd: head dim %d not in {40,64,80,160}", Dh);
     TF_ARG(K > 0 && S > 0 && H > 0 && S % 8 == 0 && ld >= (int64_t)H * Dh && ld % 8 == 0, TF_ERR_SHAPE,
            "tf_ext_attn_fwd: K=%d S=%d H=%d ld=%lld (S, ld multiples of 8; ld >= H*Dh)", K, S, H, (long long)ld);
+    TF_ARG(Kq > 0 && q_frame0 >= 0 && q_frame0 + Kq <= K, TF_ERR_SHAPE,
+           "tf_ext_attn_fwd: query frames [%d, %d) outside the %d-frame bank", q_frame0, q_frame0 + Kq, K);
     TF_ARG(tf_aligned16(q) && tf_aligned16(k) && tf_aligned16(v) && tf_aligned16(out) && tf_aligned16(ws),
            TF_ERR_ALIGN, "tf_ext_attn_fwd: tensors not 16-byte aligned");
     TF_ARG(ws_bytes >= tf_ext_attn_workspace_bytes(K, S, H, Dh, dtype), TF_ERR_WORKSPACE,
@@ -360,6 +362,8 @@ extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void
     p.vt = ws;
     p.out = out;
     p.K = K;
+    p.Kq = Kq;
+    p.q_frame0 = q_frame0;
     p.S = S;
     p.H = H;
     p.Spad = ((S + 63) / 64) * 64;

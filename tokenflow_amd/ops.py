@@ -38,15 +38,17 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 
 def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float,
-             inject: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Extended attention core (tokenflow_utils.py:124-197).  q,k,v: [3K,S,D] bf16/f16, last dim
-    contiguous, equal token stride.  Returns [3K,S,D] in the same dtype."""
+             inject: bool, out: Optional[torch.Tensor] = None, q_frame0: int = 0) -> torch.Tensor:
+    """Extended attention core (tokenflow_utils.py:124-197).  k,v: [3K,S,D] bf16/f16 (the bank),
+    q: [3Kq,S,D] = the queries of keyframes q_frame0..q_frame0+Kq-1 (Kq = K on one GPU); last dim
+    contiguous, equal token stride.  Returns [3Kq,S,D] in the same dtype."""
     _need_gpu(q, k, v)
     lib = _lib.load()
-    B, S, D = q.shape
-    if B % 3 or D % heads:
-        raise ValueError(f"ext_attn: batch {B} must be 3*K and D {D} divisible by heads {heads}")
-    K, dh = B // 3, D // heads
+    B, S, D = k.shape
+    Bq = q.shape[0]
+    if B % 3 or Bq % 3 or D % heads or q.shape[1:] != k.shape[1:] or v.shape != k.shape:
+        raise ValueError(f"ext_attn: bad shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)} heads {heads}")
+    K, Kq, dh = B // 3, Bq // 3, D // heads
     dt = _DT.get(q.dtype)
     if dt is None or dt == _lib.TF_F32 or k.dtype != q.dtype or v.dtype != q.dtype:
         raise TypeError(f"ext_attn: q/k/v must share dtype bf16 or f16, got {q.dtype},{k.dtype},{v.dtype}")
@@ -61,10 +63,11 @@ def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scal
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         ld = D
     if out is None:
-        out = torch.empty(B, S, D, dtype=q.dtype, device=q.device)
+        out = torch.empty(Bq, S, D, dtype=q.dtype, device=q.device)
     nbytes = lib.tf_ext_attn_workspace_bytes(K, S, heads, dh, dt)
     ws = _workspace(nbytes, q.device)
-    _lib.check(lib.tf_ext_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), K, S, heads, dh,
+    _lib.check(lib.tf_ext_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), K, Kq, int(q_frame0),
+                                   S, heads, dh,
                                    ld, float(scale), int(bool(inject)), dt, ws.data_ptr(), ws.numel(), _stream()),
                "tf_ext_attn_fwd")
     return out
