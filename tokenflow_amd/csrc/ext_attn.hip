@@ -86,12 +86,19 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const typename T::elem* __
     }
 }
 
-template <typename T, int DH>
-__global__ __launch_bounds__(256) void ext_attn_kernel(AttnParams p) {
+// QT = 32-query tiles per wave (1 or 2): a workgroup covers 128*QT queries.
+template <typename T, int DH, int QT>
+__global__ __launch_bounds__(256, (DH > 80 ? 1 : 2)) void ext_attn_kernel(AttnParams p) {
     typedef AttnCfg<DH> C;
     typedef typename T::elem E;
     typedef typename T::vec8 vec8;
     typedef typename T::vec4 vec4;
+    // When the head dim is not a multiple of 32 the last PV M-tile has unused rows: row DH of the
+    // V^T image is set to 1.0, so that accumulator row collects sum_k P[k] -- the softmax
+    // denominator comes out of the MFMA for free, summed over the SAME rounded P as the numerator.
+    constexpr bool ONES = (DH % 32) != 0;
+    constexpr int ONES_R = ((DH % 32) & 3) + 4 * ((DH % 32) >> 3);  // C/D register of row DH%32 (lane half 0)
+    static_assert(!ONES || ((DH % 32) & 4) == 0, "row DH must live in lane half 0");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     auto sK = [&](int b) { return reinterpret_cast<E*>(smem) + b * (C::K_ELEMS + C::V_ELEMS); };
@@ -132,7 +139,8 @@ __global__ __launch_bounds__(256) void ext_attn_kernel(AttnParams p) {
     const int64_t vt_row = (int64_t)K * p.Spad;
     const E* vg = reinterpret_cast<const E*>(p.vt) + ((int64_t)(b * H + h) * DH) * vt_row;
 
-    // ---- zero the LDS pads once: K columns DH..DKP-1 and V^T rows DH..VROWS-1 (never staged)
+    // ---- LDS pads, written once and never staged over: K columns DH..DKP-1 = 0,
+    //      V^T rows DH..VROWS-1 = 0 except row DH = 1 (denominator row) when ONES.
     if constexpr (C::DKP > DH) {
         for (int id = tid; id < 2 * 64 * (C::DKP - DH); id += 256) {
             const int bufi = id / (64 * (C::DKP - DH));
@@ -144,20 +152,23 @@ __global__ __launch_bounds__(256) void ext_attn_kernel(AttnParams p) {
         for (int id = tid; id < 2 * (C::VROWS - DH) * 64; id += 256) {
             const int bufi = id / ((C::VROWS - DH) * 64);
             const int r = (id >> 6) % (C::VROWS - DH), cidx = id & 63;
-            sV(bufi)[(DH + r) * C::VROW + cidx] = (E)0.f;
+            sV(bufi)[(DH + r) * C::VROW + cidx] = (E)((ONES && r == 0) ? 1.f : 0.f);
         }
     }
 
     // ---- Q fragments (B operand of S^T = K Q^T), resident for the whole kernel
-    const int q_row = qt * 128 + wave * 32 + l31;
-    const bool q_ok = q_row < S;
-    vec8 qf[C::KS];
-    {
-        const E* qp = qg + (((int64_t)bq * Kq + f) * S + (q_ok ? q_row : S - 1)) * p.ld + h * DH;
+    int q_row[QT];
+    bool q_ok[QT];
+    vec8 qf[QT][C::KS];
+#pragma unroll
+    for (int qi = 0; qi < QT; ++qi) {
+        q_row[qi] = qt * (128 * QT) + (wave * QT + qi) * 32 + l31;
+        q_ok[qi] = q_row[qi] < S;
+        const E* qp = qg + (((int64_t)bq * Kq + f) * S + (q_ok[qi] ? q_row[qi] : S - 1)) * p.ld + h * DH;
 #pragma unroll
         for (int t = 0; t < C::KS; ++t) {
             const int col = 16 * t + 8 * hi;
-            qf[t] = __builtin_bit_cast(vec8, col < DH ? ld16(qp + col) : u32x4{0, 0, 0, 0});
+            qf[qi][t] = __builtin_bit_cast(vec8, col < DH ? ld16(qp + col) : u32x4{0, 0, 0, 0});
         }
     }
 
@@ -200,17 +211,21 @@ __global__ __launch_bounds__(256) void ext_attn_kernel(AttnParams p) {
         }
     };
 
-    f32x16 o[C::MT];
+    f32x16 o[QT][C::MT];
+    float m_run[QT], l_run[QT];  // running max of the RAW scores (scale > 0); this lane's share of the denominator
 #pragma unroll
-    for (int mt = 0; mt < C::MT; ++mt)
+    for (int qi = 0; qi < QT; ++qi) {
+        m_run[qi] = -INFINITY;
+        l_run[qi] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[mt][r] = 0.f;
-    float m_run = -INFINITY;  // running max of the RAW scores (scale > 0)
-    float l_run = 0.f;        // this lane's share of the softmax denominator
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qi][mt][r] = 0.f;
+    }
     const float c = p.c;
 
     stage_load(0);
-    __syncthreads();  // pad zero-fill visible before anything reads; staging regions are disjoint from the pads
+    __syncthreads();  // pad fill visible before anything reads; staging regions are disjoint from the pads
     stage_write(0);
     __syncthreads();
 
@@ -219,16 +234,21 @@ __global__ __launch_bounds__(256) void ext_attn_kernel(AttnParams p) {
         const bool has_next = tile + 1 < ntiles;
         if (has_next) stage_load(tile + 1);
 
-        // ---- S^T tile: 64 keys x 32 queries per wave
-        f32x16 s[2];
+        // ---- S^T tile: 64 keys x 32*QT queries per wave; each K fragment feeds QT MFMAs
+        f32x16 s[QT][2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+            for (int qi = 0; qi < QT; ++qi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[qi][kt][r] = 0.f;
             const E* krow = sK(buf) + (kt * 32 + l31) * C::KROW + 8 * hi;
 #pragma unroll
-            for (int t = 0; t < C::KS; ++t)
-                s[kt] = T::mfma32(__builtin_bit_cast(vec8, ld16(krow + 16 * t)), qf[t], s[kt]);
+            for (int t = 0; t < C::KS; ++t) {
+                const vec8 kfrag = __builtin_bit_cast(vec8, ld16(krow + 16 * t));
+#pragma unroll
+                for (int qi = 0; qi < QT; ++qi) s[qi][kt] = T::mfma32(kfrag, qf[qi][t], s[qi][kt]);
+            }
         }
         if (ragged) {
             const int tt = tile - (tile / tpf) * tpf;
@@ -237,44 +257,57 @@ __global__ __launch_bounds__(256) void ext_attn_kernel(AttnParams p) {
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (tt * 64 + kt * 32 + cd_row(r, hi) >= S) s[kt][r] = -INFINITY;
+                        if (tt * 64 + kt * 32 + cd_row(r, hi) >= S) {
+#pragma unroll
+                            for (int qi = 0; qi < QT; ++qi) s[qi][kt][r] = -INFINITY;
+                        }
             }
         }
 
         // ---- online softmax (lane-local; the two lanes of a query share m)
-        float mx = s[0][0];
+        vec8 pf[QT][4];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int qi = 0; qi < QT; ++qi) {
+            float mx = s[qi][0][0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);  // exp2(-inf) = 0 on the first tile
-        const float mc = m_new * c;
-        m_run = m_new;
-        float lsum = 0.f;
-        vec8 pf[4];
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qi][kt][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            // rescale only when some query of this wave saw a new maximum: alpha == 1 exactly otherwise
+            if (__any(mx > m_run[qi])) {
+                const float m_new = fmaxf(m_run[qi], mx);
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);  // exp2(-inf) = 0 on tile 0
+                m_run[qi] = m_new;
+                if constexpr (!ONES) l_run[qi] *= alpha;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c, -mc));
-                lsum += pv;
-                pf[kt * 2 + (r >> 3)][r & 7] = (E)pv;
+                for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[qi][mt][r] *= alpha;
             }
-        l_run = fmaf(l_run, alpha, lsum);
+            const float mc = m_run[qi] * c;
+            float lsum = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[qi][kt][r], c, -mc));
+                    if constexpr (!ONES) lsum += pv;
+                    pf[qi][kt * 2 + (r >> 3)][r & 7] = (E)pv;
+                }
+            if constexpr (!ONES) l_run[qi] += lsum;
+        }
 
-        // ---- O^T += V^T . P
+        // ---- O^T += V^T . P ; each V^T fragment feeds QT MFMAs
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt) {
             const E* vrow = sV(buf) + (mt * 32 + l31) * C::VROW + 8 * hi;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                o[mt] = T::mfma32(__builtin_bit_cast(vec8, ld16(vrow + 16 * ks)), pf[ks], o[mt]);
+            for (int ks = 0; ks < 4; ++ks) {
+                const vec8 vfrag = __builtin_bit_cast(vec8, ld16(vrow + 16 * ks));
+#pragma unroll
+                for (int qi = 0; qi < QT; ++qi) o[qi][mt] = T::mfma32(vfrag, pf[qi][ks], o[qi][mt]);
+            }
         }
 
         if (has_next) stage_write(buf ^ 1);
@@ -282,28 +315,47 @@ __global__ __launch_bounds__(256) void ext_attn_kernel(AttnParams p) {
     }
 
     // ---- epilogue: normalise, round, store 4 consecutive d (8 B) per register group
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv_l = 1.0f / l_tot;
-    if (q_ok) {
-        E* op = reinterpret_cast<E*>(p.out) + (((int64_t)b * Kq + f) * S + q_row) * ((int64_t)H * DH) + h * DH;
 #pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt)
+    for (int qi = 0; qi < QT; ++qi) {
+        float l_tot;
+        if constexpr (ONES)
+            l_tot = __shfl(o[qi][C::MT - 1][ONES_R], l31);  // row DH lives in lane half 0 of the last M-tile
+        else
+            l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32);
+        const float inv_l = 1.0f / l_tot;
+        if (q_ok[qi]) {
+            E* op = reinterpret_cast<E*>(p.out) + (((int64_t)b * Kq + f) * S + q_row[qi]) * ((int64_t)H * DH) + h * DH;
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int d0 = mt * 32 + 8 * rg + 4 * hi;
-                if (d0 < DH) {
-                    vec4 w;
+            for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) w[i] = (E)(o[mt][rg * 4 + i] * inv_l);
-                    *reinterpret_cast<u32x2*>(op + d0) = __builtin_bit_cast(u32x2, w);
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int d0 = mt * 32 + 8 * rg + 4 * hi;
+                    if (d0 < DH) {
+                        vec4 w;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) w[i] = (E)(o[qi][mt][rg * 4 + i] * inv_l);
+                        *reinterpret_cast<u32x2*>(op + d0) = __builtin_bit_cast(u32x2, w);
+                    }
                 }
-            }
+        }
     }
+}
+
+template <typename T, int DH, int QT>
+int launch_attn_qt(AttnParams p, hipStream_t st) {
+    typedef AttnCfg<DH> C;
+    auto kern = ext_attn_kernel<T, DH, QT>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)C::LDS_BYTES);
+    p.nQT = (p.S + 128 * QT - 1) / (128 * QT);
+    const unsigned grid = (unsigned)(3 * p.Kq * p.nQT * p.H);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, st, p);
+    TF_LAUNCH_CHECK("tf_ext_attn_fwd");
+    return 0;
 }
 
 template <typename T, int DH>
 int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
-    typedef AttnCfg<DH> C;
     typedef typename T::elem E;
     // pre-pass: V -> transposed, key-permuted, per-frame padded bank
     {
@@ -313,13 +365,12 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
                            reinterpret_cast<E*>(const_cast<void*>(p.vt)), p.K, p.S, p.H, DH, p.Spad, p.ld);
         TF_LAUNCH_CHECK("tf_ext_attn_fwd(vt_pack)");
     }
-    auto kern = ext_attn_kernel<T, DH>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)C::LDS_BYTES);
-    const unsigned grid = (unsigned)(3 * p.Kq * p.nQT * p.H);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, st, p);
-    TF_LAUNCH_CHECK("tf_ext_attn_fwd");
-    return 0;
+    // 64 queries per wave (each K / V^T fragment read from LDS feeds two MFMAs) when the register
+    // budget allows it (head dim <= 64) and the 256-query tiles still fill the chip
+    if constexpr (DH <= 64) {
+        if (p.S >= 512) return launch_attn_qt<T, DH, 2>(p, st);
+    }
+    return launch_attn_qt<T, DH, 1>(p, st);
 }
 
 template <typename T>
