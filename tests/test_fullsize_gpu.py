@@ -1,0 +1,200 @@
+"""Parity at BASELINE.json's full sizes (cfg2: 40 frames, 512x512, SD1.5, K=8 keyframes, n=5;
+cfg4 geometry for the NN search) through size-independent properties and oracle checks on
+sampled rows -- the full score matrices the oracle would need do not fit anywhere
+(4 GiB per head and branch at cfg2 level 0).  Needs an MI355X.
+
+Stated tolerance for the attention at these shapes: per-token deviation < 1e-3 (north star),
+inputs N(0,1) rounded to bf16, oracle fed the same rounded values -- except where the bf16
+OUTPUT format itself cannot represent the reference to 1e-3: bf16 has 8 significand bits, so an
+output of magnitude |o| carries a rounding error up to 2^-8*|o| (> 1e-3 once |o| > 0.256; this
+happens on the short source-branch problems of the 16x16 level, S = 256 keys).  The asserted
+bound is therefore  |out - ref| < max(1e-3, 2^-8*|ref| + 2e-4)  per element."""
+import pytest
+import torch
+
+from oracle import tokenflow_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from tokenflow_amd import ops
+    return ops
+
+
+def _oracle_rows(q, k, v, K, S, h, d, b, f, head, rows, inject):
+    """fp32 oracle for a few query rows of one (branch, frame, head): tokenflow_utils.py:173-179."""
+    D = h * d
+    qv, kv, vv = (t.view(3, K, S, h, d) for t in (q, k, v))
+    bq = 0 if (inject and b > 0) else b
+    qr = qv[bq, f, rows, head].float()                                   # [R, d]
+    if b == 0:
+        kk, vals = kv[0, f, :, head].float(), vv[0, f, :, head].float()  # own S keys
+    else:
+        kk, vals = kv[bq, :, :, head].reshape(K * S, d).float(), vv[b, :, :, head].reshape(K * S, d).float()
+    p = torch.softmax(qr @ kk.T * d ** -0.5, dim=-1)
+    return p @ vals                                                      # [R, d]
+
+
+@pytest.mark.parametrize("level", [0, 1, 2])
+@pytest.mark.parametrize("inject", [False, True])
+def test_ext_attn_cfg2_sampled_rows(level, inject):
+    ops = _ops()
+    K, h = 8, 8
+    S, D = [(4096, 320), (1024, 640), (256, 1280)][level]
+    d = D // h
+    g = torch.Generator(device="cuda").manual_seed(100 + level)
+    q, k, v = (torch.randn(3 * K, S, D, generator=g, device="cuda").bfloat16() for _ in range(3))
+    out = ops.ext_attn(q, k, v, h, d ** -0.5, inject)
+    torch.cuda.synchronize()
+    qc, kc, vc, oc = q.cpu(), k.cpu(), v.cpu(), out.float().cpu().view(3, K, S, h, d)
+    rows = torch.tensor([0, 1, 31, 32, 63, 64, 127, 128, S // 2 + 5, S - 129, S - 2, S - 1])
+    worst, worst_excess = 0.0, -1.0
+    for b, f, head in [(0, 0, 0), (0, K - 1, h - 1), (1, 0, 3), (1, K - 1, 0), (2, 3, h - 1), (2, K - 2, 5)]:
+        ref = _oracle_rows(qc, kc, vc, K, S, h, d, b, f, head, rows, inject)
+        err = (oc[b, f, rows, head] - ref).abs()
+        bound = torch.clamp(2.0 ** -8 * ref.abs() + 2e-4, min=1e-3)
+        worst = max(worst, float(err.max()))
+        worst_excess = max(worst_excess, float((err - bound).max()))
+    assert worst_excess < 0, f"level {level} inject {inject}: max per-token deviation {worst:.3e}"
+    if level < 2:          # thousands of keys: |out| is small and the plain north-star number holds
+        assert worst < 1e-3, f"level {level} inject {inject}: max per-token deviation {worst:.3e}"
+
+
+def test_ext_attn_injection_equals_aliased_inputs():
+    """inject=True must be bit-identical to running without injection on tensors whose uncond/cond
+    q and k were overwritten by the source branch's (what the reference does in place, 124-130)."""
+    ops = _ops()
+    K, S, h, d = 8, 1024, 8, 80
+    g = torch.Generator(device="cuda").manual_seed(7)
+    q, k, v = (torch.randn(3 * K, S, h * d, generator=g, device="cuda").bfloat16() for _ in range(3))
+    a = ops.ext_attn(q, k, v, h, d ** -0.5, True)
+    q2, k2 = q.clone(), k.clone()
+    q2[K:2 * K], q2[2 * K:], k2[K:2 * K], k2[2 * K:] = q[:K], q[:K], k[:K], k[:K]
+    b = ops.ext_attn(q2, k2, v, h, d ** -0.5, False)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("S,h,d", [(4096, 8, 40), (4096, 5, 64)])
+def test_ext_attn_rows_sum_to_one(S, h, d):
+    """V = 1 everywhere => every output element is sum(P)/sum(P) = 1 (exact when the denominator
+    comes from the same MFMA as the numerator, within 2^-7 otherwise)."""
+    ops = _ops()
+    K = 4
+    g = torch.Generator(device="cuda").manual_seed(3)
+    q, k = (torch.randn(3 * K, S, h * d, generator=g, device="cuda").bfloat16() for _ in range(2))
+    out = ops.ext_attn(q, k, torch.ones_like(q), h, d ** -0.5, False).float()
+    assert float((out - 1).abs().max()) <= (0.0 if d % 32 else 2.0 ** -7)
+
+
+def _videolike(K, n, S, D, chunk, g):
+    ln = torch.nn.functional.layer_norm
+    piv = ln(torch.randn(K, S, D, generator=g, device="cuda"), (D,)).bfloat16()
+    perm = torch.stack([torch.randperm(S, generator=g, device="cuda") for _ in range(n)])
+    tgt = (piv[chunk].float()[perm.reshape(-1)] + 0.1 * torch.randn(n * S, D, generator=g, device="cuda")).bfloat16()
+    return piv, tgt, perm.reshape(-1)
+
+
+def test_nn_search_cfg2_level0_full_oracle():
+    """Full-size chunk (20480 targets x 2 keyframes x 4096 pivots, D=320) against the fp32 oracle."""
+    ops = _ops()
+    K, n, S, D, c = 8, 5, 4096, 320, 3
+    g = torch.Generator(device="cuda").manual_seed(11)
+    piv, tgt, perm = _videolike(K, n, S, D, c, g)
+    idx = ops.nn_search(tgt, piv, ops.pivot_inv_norm(piv), [c, c - 1]).cpu()
+    assert torch.equal(idx[0].long(), perm.cpu())            # keyframe c: the planted permutation
+    ref_idx, sim = orc.nn_search(tgt.float().cpu().view(n, S, D), piv.float().cpu(), c)
+    n_bad = 0
+    for p, (r, s) in enumerate(zip(ref_idx, sim.chunk(2, dim=1))):
+        _, bad = orc.nn_mismatch_tie_aware(s, r, idx[p], 1e-5)
+        n_bad += bad
+    assert n_bad == 0
+
+
+def test_nn_search_cfg4_level0_planted_and_sampled():
+    """cfg4 geometry (S=9216, n=8: 73728 targets, 5 GiB similarity matrix in the reference):
+    planted permutation for keyframe c, sampled target rows against the oracle for keyframe c-1."""
+    ops = _ops()
+    K, n, S, D, c = 3, 8, 9216, 320, 2
+    g = torch.Generator(device="cuda").manual_seed(13)
+    piv, tgt, perm = _videolike(K, n, S, D, c, g)
+    idx = ops.nn_search(tgt, piv, ops.pivot_inv_norm(piv), [c, c - 1]).cpu()
+    assert torch.equal(idx[0].long(), perm.cpu())
+    rows = torch.randint(0, n * S, (512,), generator=torch.Generator().manual_seed(1))
+    sim = orc.batch_cosine_sim(tgt[rows.cuda()].float().cpu(), piv[c - 1].float().cpu())
+    _, bad = orc.nn_mismatch_tie_aware(sim, sim.argmax(-1), idx[1][rows], 1e-5)
+    assert bad == 0
+
+
+@pytest.mark.parametrize("P", [1, 2])
+def test_gather_blend_cfg2_level0_bit_exact(P):
+    ops = _ops()
+    K, n, S, D = 8, 5, 4096, 320
+    g = torch.Generator().manual_seed(5)
+    kf_out = torch.randn(3 * K, S, D, generator=g).bfloat16()
+    res = torch.randn(3 * n, S, D, generator=g).bfloat16()
+    c = 4 if P == 2 else 0
+    idx = [torch.randint(0, S, (n * S,), generator=g) for _ in range(P)]
+    ref = orc.gather_blend(kf_out, idx, c, n, residual=res)
+    out = ops.gather_blend(kf_out.cuda(), torch.stack(idx).int().cuda(),
+                           orc.blend_weights(n, 1).cuda() if P == 2 else None, orc.keyframe_ids(c), n,
+                           res.cuda(), ref.dtype)
+    assert out.dtype == ref.dtype and torch.equal(out.cpu(), ref)
+
+
+def test_hooks_on_gpu_match_cpu_reference_numerics():
+    """The drop-in hooks on the GPU (real HIP ops) vs the same hooks on the CPU with the
+    oracle-backed FakeOps in bf16-rounding mode: identical op boundaries, so the outputs agree to
+    kernel tolerance.  Chunk inputs are video-like (far from NN ties)."""
+    import tokenflow_utils as tfu
+    from tests import fake_diffusers as fd
+    from tests.fake_ops import FakeOps
+    from tokenflow_amd import hooks
+
+    def build():
+        torch.manual_seed(0)
+        blk = fd.BasicTransformerBlock(320, 8, cross_dim=32).eval()
+        holder = torch.nn.Module()
+        holder.unet = torch.nn.Module()
+        holder.unet.blk = blk
+        return holder, blk
+
+    K, n, S = 3, 2, 192
+    g = torch.Generator().manual_seed(1)
+    x_piv = torch.randn(3 * K, S, 320, generator=g)
+    enc, enc_n = torch.randn(3 * K, 7, 32, generator=g), torch.randn(3 * n, 7, 32, generator=g)
+    chunks = []
+    for c in range(K):
+        perm = torch.randperm(S, generator=g)
+        src = x_piv.view(3, K, S, 320)[0, c][perm][None].repeat(n, 1, 1) + 0.02 * torch.randn(n, S, 320, generator=g)
+        chunks.append(torch.cat([src, torch.randn(2 * n, S, 320, generator=g)]))
+
+    def run(dev, ops_obj):
+        holder, blk = build()
+        holder.to(dev)
+        old = hooks.ops
+        hooks.ops = ops_obj if ops_obj is not None else old
+        try:
+            for m in (blk.attn1,):
+                m.forward = hooks._make_sa_forward(m, pnp=True)
+                hooks._set_schedule(m, [5])
+                m.t = 5
+            tfu.set_tokenflow(holder)
+            outs = []
+            with torch.no_grad():
+                tfu.register_pivotal(holder, True)
+                outs.append(blk(x_piv.to(dev), encoder_hidden_states=enc.to(dev)))
+                tfu.register_pivotal(holder, False)
+                for c in range(K):
+                    tfu.register_batch_idx(holder, c)
+                    outs.append(blk(chunks[c].to(dev), encoder_hidden_states=enc_n.to(dev)))
+            return [o.float().cpu() for o in outs]
+        finally:
+            hooks.ops = old
+
+    gpu = run("cuda", None)
+    cpu = run("cpu", FakeOps(round16=True))
+    for i, (a, b) in enumerate(zip(gpu, cpu)):
+        assert a.shape == b.shape
+        err = float((a - b).abs().max())
+        assert err < 2e-2, f"pass {i}: {err}"
