@@ -94,13 +94,17 @@ int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void* out,
  *   first maximal j wins (torch.argmax).  The 1/||tgt[t]|| factor of util.py:66
  *   is a positive per-row constant and cannot change the argmax, so targets are
  *   never normalised.  idx is int32 [P, n_tgt].  D multiple of 8; dtype bf16/f16.
+ *   ws: scratch for per-split candidates when the pivot range is split over workgroups
+ *   (size from tf_nn_search_workspace_bytes, >= 256 bytes).
  * ------------------------------------------------------------------------ */
 int tf_pivot_inv_norm(const void* piv, float* inv_norm, int64_t rows, int D, int dtype,
                       void* stream);
 
+size_t tf_nn_search_workspace_bytes(int64_t n_tgt, int S, int D, int P);
+
 int tf_nn_search(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx,
                  int64_t n_tgt, int S, int D, int P, int kf0, int kf1, int dtype,
-                 void* stream);
+                 void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Gather + blend + residual  --  replaces tokenflow_utils.py:362-397

@@ -15,9 +15,22 @@
 //               with ((row >> 1) & 7) -> conflict-free ds_read_b128 fragment reads
 //   pipeline  = global->register prefetch of chunk i+1 issued before the MFMAs of
 //               chunk i, LDS write after them, one barrier per chunk.
+// Two kernels share that epilogue:
+//   nn_search_rb_kernel<T, DK>  (D = 16*DK <= 320): the wave's 32 target rows live in REGISTERS as
+//               MFMA B fragments for the whole kernel (80 VGPRs at D = 320), so only the pivot
+//               tiles [32][D] stream through LDS (one ds_read_b128 per MFMA, no target restaging).
+//   nn_search_kernel<T, WN>     (any D): both operands staged in 64-wide D chunks.
+// Parallelism: grid = (target panels, P keyframes, SPLITS of the pivot range).  With SPLITS > 1
+// every workgroup writes its (best score, index) per target to scratch and nn_finalize_kernel
+// merges them in ascending split order (strict '>', so the first index still wins on ties).
 #include "tf_common.h"
 
 namespace {
+
+struct NnPartial {
+    float v;
+    int i;
+};
 
 constexpr int TM = 128;  // pivots per tile
 constexpr int BK = 64;   // D chunk
@@ -59,8 +72,9 @@ template <typename T, int WN>
 __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* __restrict__ tgt,
                                                         const typename T::elem* __restrict__ piv,
                                                         const float* __restrict__ inv_norm,
-                                                        int32_t* __restrict__ idx_out, int64_t n_tgt, int S,
-                                                        int D, int kf0, int kf1) {
+                                                        int32_t* __restrict__ idx_out,
+                                                        NnPartial* __restrict__ part_out, int64_t n_tgt, int S,
+                                                        int D, int kf0, int kf1, int tiles_per_split) {
     typedef typename T::vec8 vec8;
     constexpr int TN = 64 * WN;
     constexpr int A_BYTES = TM * 128;
@@ -89,7 +103,9 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
     const float* inv = inv_norm + (int64_t)kf * S;
     const int64_t t0 = (int64_t)blockIdx.x * TN;
 
-    const int n_mt = (S + TM - 1) / TM;
+    const int n_mt_all = (S + TM - 1) / TM;
+    const int mt0 = blockIdx.z * tiles_per_split;           // this workgroup's slice of the pivot tiles
+    const int n_mt = min(tiles_per_split, n_mt_all - mt0);
     const int n_kc = (D + BK - 1) / BK;
     const int total = n_mt * n_kc;
 
@@ -104,7 +120,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
         for (int i = 0; i < NPA; ++i) {
             const int id = tid + 256 * i;
             const int r = id >> 3, pc = id & 7;
-            int row = mt * TM + r;
+            int row = (mt0 + mt) * TM + r;
             row = row < S ? row : S - 1;  // clamped duplicates can never win (see epilogue)
             const int col = col0 + pc * 8;
             ra[i] = col < D ? ld16(pv + (int64_t)row * D + col) : u32x4{0, 0, 0, 0};
@@ -119,7 +135,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
             rb[i] = col < D ? ld16(tgt + row * D + col) : u32x4{0, 0, 0, 0};
         }
         if (kc == 0 && tid < TM) {
-            int row = mt * TM + tid;
+            int row = (mt0 + mt) * TM + tid;
             row = row < S ? row : S - 1;
             rinv = inv[row];
         }
@@ -190,7 +206,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
                 for (int r = 0; r < 16; ++r) {
                     const int rl = wr * 64 + i * 32 + cd_row(r, hi);
                     const float w = si[rl];
-                    const int gi = mt * TM + rl;
+                    const int gi = (mt0 + mt) * TM + rl;
 #pragma unroll
                     for (int j = 0; j < WN; ++j) {
                         const float sc = acc[i][j][r] * w;
@@ -225,25 +241,222 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
     if (tid < TN) {
         float v0 = sBestV[tid], v1 = sBestV[TN + tid];
         int i0 = sBestI[tid], i1 = sBestI[TN + tid];
-        if (v1 > v0 || (v1 == v0 && i1 < i0)) i0 = i1;
+        if (v1 > v0 || (v1 == v0 && i1 < i0)) {
+            i0 = i1;
+            v0 = v1;
+        }
         i0 = i0 < S ? i0 : S - 1;  // a clamped duplicate of row S-1 maps back to S-1
         const int64_t t = t0 + tid;
-        if (t < n_tgt) idx_out[(int64_t)p * n_tgt + t] = i0;
+        if (t < n_tgt) {
+            if (part_out)
+                part_out[((int64_t)blockIdx.z * gridDim.y + p) * n_tgt + t] = NnPartial{v0, i0};
+            else
+                idx_out[(int64_t)p * n_tgt + t] = i0;
+        }
     }
 }
 
+// ---------------------------------------------------------------------------
+// Register-B variant for D = 16*DK: one wave = 32 targets whose B fragments stay in registers.
+template <typename T, int DK>
+__global__ __launch_bounds__(256, 3) void nn_search_rb_kernel(const typename T::elem* __restrict__ tgt,
+                                                           const typename T::elem* __restrict__ piv,
+                                                           const float* __restrict__ inv_norm,
+                                                           int32_t* __restrict__ idx_out,
+                                                           NnPartial* __restrict__ part_out, int64_t n_tgt, int S,
+                                                           int kf0, int kf1, int tiles_per_split) {
+    typedef typename T::elem E;
+    typedef typename T::vec8 vec8;
+    constexpr int D = 16 * DK;
+    constexpr int TMR = 32;                  // pivots per tile
+    constexpr int RS = D + 8;                // LDS row stride (elements): odd number of 16-B slots
+    constexpr int PPR = D / 8;               // 16-B pieces per row
+    constexpr int NP = (TMR * PPR + 255) / 256;
+    constexpr int A_ELEMS = TMR * RS;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    auto sA = [&](int b) { return reinterpret_cast<E*>(smem) + b * A_ELEMS; };
+    float* sInv = reinterpret_cast<float*>(smem + 2 * A_ELEMS * sizeof(E));  // [2][TMR]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int hi = lane >> 5;
+    const int l31 = lane & 31;
+    const int p = blockIdx.y;
+    const int kf = p == 0 ? kf0 : kf1;
+    const E* pv = piv + (int64_t)kf * S * D;
+    const float* inv = inv_norm + (int64_t)kf * S;
+    const int64_t t_row = (int64_t)blockIdx.x * 128 + wave * 32 + l31;
+
+    const int n_mt_all = (S + TMR - 1) / TMR;
+    const int mt0 = blockIdx.z * tiles_per_split;
+    const int n_mt = min(tiles_per_split, n_mt_all - mt0);
+
+    vec8 fb[DK];
+    {
+        const E* tp = tgt + (t_row < n_tgt ? t_row : n_tgt - 1) * D + 8 * hi;
+#pragma unroll
+        for (int t = 0; t < DK; ++t) fb[t] = __builtin_bit_cast(vec8, ld16(tp + 16 * t));
+    }
+
+    u32x4 ra[NP];
+    float rinv = 0.f;
+    auto stage_load = [&](int mt) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int id = tid + 256 * i;
+            if (id < TMR * PPR) {
+                const int r = id / PPR, pc = id - r * PPR;
+                int row = (mt0 + mt) * TMR + r;
+                row = row < S ? row : S - 1;
+                ra[i] = ld16(pv + (int64_t)row * D + pc * 8);
+            }
+        }
+        if (tid < TMR) {
+            int row = (mt0 + mt) * TMR + tid;
+            rinv = inv[row < S ? row : S - 1];
+        }
+    };
+    auto stage_write = [&](int mt) {
+        E* a = sA(mt & 1);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int id = tid + 256 * i;
+            if (id < TMR * PPR) {
+                const int r = id / PPR, pc = id - r * PPR;
+                st16(a + r * RS + pc * 8, ra[i]);
+            }
+        }
+        if (tid < TMR) sInv[(mt & 1) * TMR + tid] = rinv;
+    };
+
+    float best_v = -INFINITY;
+    int best_i = 0;
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+    for (int mt = 0; mt < n_mt; ++mt) {
+        const bool has_next = mt + 1 < n_mt;
+        if (has_next) stage_load(mt + 1);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const E* arow = sA(mt & 1) + l31 * RS + 8 * hi;
+#pragma unroll
+        for (int t = 0; t < DK; ++t) acc = T::mfma32(__builtin_bit_cast(vec8, ld16(arow + 16 * t)), fb[t], acc);
+        const float* si = sInv + (mt & 1) * TMR;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = cd_row(r, hi);
+            const float sc = acc[r] * si[rl];
+            if (sc > best_v) {
+                best_v = sc;
+                best_i = (mt0 + mt) * TMR + rl;
+            }
+        }
+        if (has_next) stage_write(mt + 1);
+        __syncthreads();
+    }
+    const float ov = __shfl_xor(best_v, 32);
+    const int oi = __shfl_xor(best_i, 32);
+    if (ov > best_v || (ov == best_v && oi < best_i)) {
+        best_v = ov;
+        best_i = oi;
+    }
+    best_i = best_i < S ? best_i : S - 1;
+    if (hi == 0 && t_row < n_tgt) {
+        if (part_out)
+            part_out[((int64_t)blockIdx.z * gridDim.y + p) * n_tgt + t_row] = NnPartial{best_v, best_i};
+        else
+            idx_out[(int64_t)p * n_tgt + t_row] = best_i;
+    }
+}
+
+// merge the per-split candidates: ascending split order == ascending pivot index
+__global__ __launch_bounds__(256) void nn_finalize_kernel(const NnPartial* __restrict__ part,
+                                                          int32_t* __restrict__ idx_out, int64_t total, int splits) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    NnPartial b = part[g];
+    for (int s = 1; s < splits; ++s) {
+        const NnPartial c = part[(int64_t)s * total + g];
+        if (c.v > b.v || (c.v == b.v && c.i < b.i)) b = c;
+    }
+    idx_out[g] = b.i;
+}
+
+// Launch plan shared by the launchers and tf_nn_search_workspace_bytes.
+struct NnPlan {
+    bool rb;        // register-B kernel (D == 320)
+    bool wide;      // generic kernel with 128-target panels
+    int64_t panels;
+    int splits, tiles_per_split;
+};
+
+// splits of the pivot range so that the grid has >= ~4 workgroups per CU (1024) while every split keeps >= 1 tile
+static NnPlan nn_plan(int64_t n_tgt, int S, int D, int P) {
+    NnPlan pl;
+    pl.rb = D == 320;
+    pl.wide = !pl.rb && ((n_tgt + 127) / 128) * P >= 512;
+    const int tn = pl.rb ? 128 : (pl.wide ? 128 : 64);
+    const int tm = pl.rb ? 32 : TM;
+    pl.panels = (n_tgt + tn - 1) / tn;
+    const int n_tiles = (S + tm - 1) / tm;
+    int splits = 1;
+    while (pl.panels * P * splits < 1024 && splits * 2 <= n_tiles) splits *= 2;
+    pl.tiles_per_split = (n_tiles + splits - 1) / splits;
+    pl.splits = (n_tiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
+    return pl;
+}
+
+static int finalize(const NnPartial* part, int32_t* idx, int64_t total, int splits, hipStream_t st) {
+    hipLaunchKernelGGL(nn_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, idx, total,
+                       splits);
+    TF_LAUNCH_CHECK("tf_nn_search(finalize)");
+    return 0;
+}
+
 template <typename T, int WN>
-int launch_nn(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, int64_t n_tgt, int S, int D,
-              int P, int kf0, int kf1, hipStream_t st) {
+int launch_nn(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, NnPartial* ws, int64_t n_tgt,
+              int S, int D, int P, int kf0, int kf1, hipStream_t st) {
     constexpr int TN = 64 * WN;
     const size_t lds = 2 * (TM * 128 + TN * 128) + 2 * TM * 4 + 2 * TN * 8;
-    dim3 grid((unsigned)((n_tgt + TN - 1) / TN), (unsigned)P);
+    const NnPlan pl = nn_plan(n_tgt, S, D, P);
+    const int splits = pl.splits, tps = pl.tiles_per_split;
+    dim3 grid((unsigned)pl.panels, (unsigned)P, (unsigned)splits);
     auto kern = nn_search_kernel<T, WN>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, reinterpret_cast<const typename T::elem*>(tgt),
-                       reinterpret_cast<const typename T::elem*>(piv), inv_norm, idx, n_tgt, S, D, kf0, kf1);
+                       reinterpret_cast<const typename T::elem*>(piv), inv_norm, idx, splits > 1 ? ws : nullptr, n_tgt,
+                       S, D, kf0, kf1, tps);
     TF_LAUNCH_CHECK("tf_nn_search");
-    return 0;
+    return splits > 1 ? finalize(ws, idx, n_tgt * P, splits, st) : 0;
+}
+
+template <typename T, int DK>
+int launch_nn_rb(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, NnPartial* ws, int64_t n_tgt,
+                 int S, int P, int kf0, int kf1, hipStream_t st) {
+    constexpr int D = 16 * DK;
+    const size_t lds = 2 * 32 * (D + 8) * 2 + 2 * 32 * 4;
+    const NnPlan pl = nn_plan(n_tgt, S, D, P);
+    const int splits = pl.splits, tps = pl.tiles_per_split;
+    dim3 grid((unsigned)pl.panels, (unsigned)P, (unsigned)splits);
+    hipLaunchKernelGGL((nn_search_rb_kernel<T, DK>), grid, dim3(256), lds, st,
+                       reinterpret_cast<const typename T::elem*>(tgt), reinterpret_cast<const typename T::elem*>(piv),
+                       inv_norm, idx, splits > 1 ? ws : nullptr, n_tgt, S, kf0, kf1, tps);
+    TF_LAUNCH_CHECK("tf_nn_search");
+    return splits > 1 ? finalize(ws, idx, n_tgt * P, splits, st) : 0;
+}
+
+template <typename T>
+int dispatch_nn(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, NnPartial* ws, int64_t n_tgt,
+                int S, int D, int P, int kf0, int kf1, hipStream_t st) {
+    const NnPlan pl = nn_plan(n_tgt, S, D, P);
+    if (pl.rb) return launch_nn_rb<T, 20>(tgt, piv, inv_norm, idx, ws, n_tgt, S, P, kf0, kf1, st);
+    // 128-target panels when they still give >= 2 workgroups per CU, else 64-target panels
+    return pl.wide ? launch_nn<T, 2>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st)
+                : launch_nn<T, 1>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st);
 }
 
 }  // namespace
@@ -266,19 +479,26 @@ extern "C" int tf_pivot_inv_norm(const void* piv, float* inv_norm, int64_t rows,
     return 0;
 }
 
+extern "C" size_t tf_nn_search_workspace_bytes(int64_t n_tgt, int S, int D, int P) {
+    if (n_tgt <= 0 || S <= 0 || D <= 0 || P <= 0) return 0;
+    const NnPlan pl = nn_plan(n_tgt, S, D, P);
+    const size_t bytes = pl.splits > 1 ? (size_t)pl.splits * P * n_tgt * sizeof(NnPartial) : 0;
+    return bytes < 256 ? 256 : bytes;   // never 0: the caller always passes a valid pointer
+}
+
 extern "C" int tf_nn_search(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, int64_t n_tgt,
-                            int S, int D, int P, int kf0, int kf1, int dtype, void* stream) {
-    TF_ARG(tgt && piv && inv_norm && idx, TF_ERR_NULL, "tf_nn_search: null pointer");
+                            int S, int D, int P, int kf0, int kf1, int dtype, void* ws, size_t ws_bytes,
+                            void* stream) {
+    TF_ARG(tgt && piv && inv_norm && idx && ws, TF_ERR_NULL, "tf_nn_search: null pointer");
     TF_ARG(dtype == TF_BF16 || dtype == TF_F16, TF_ERR_DTYPE, "tf_nn_search: dtype %d (bf16/f16 only)", dtype);
     TF_ARG(n_tgt > 0 && S > 0 && D > 0 && D % 8 == 0 && (P == 1 || P == 2) && kf0 >= 0 && (P == 1 || kf1 >= 0),
            TF_ERR_SHAPE, "tf_nn_search: n_tgt=%lld S=%d D=%d P=%d kf=(%d,%d)", (long long)n_tgt, S, D, P, kf0, kf1);
-    TF_ARG(tf_aligned16(tgt) && tf_aligned16(piv), TF_ERR_ALIGN, "tf_nn_search: inputs not 16-byte aligned");
+    TF_ARG(tf_aligned16(tgt) && tf_aligned16(piv) && tf_aligned16(ws), TF_ERR_ALIGN,
+           "tf_nn_search: inputs not 16-byte aligned");
+    TF_ARG(ws_bytes >= tf_nn_search_workspace_bytes(n_tgt, S, D, P), TF_ERR_WORKSPACE,
+           "tf_nn_search: workspace %zu < %zu bytes", ws_bytes, tf_nn_search_workspace_bytes(n_tgt, S, D, P));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    // 128-target panels when they still give >= 2 workgroups per CU, else 64-target panels
-    const bool wide = ((n_tgt + 127) / 128) * P >= 512;
-    if (dtype == TF_BF16)
-        return wide ? launch_nn<BF16, 2>(tgt, piv, inv_norm, idx, n_tgt, S, D, P, kf0, kf1, st)
-                    : launch_nn<BF16, 1>(tgt, piv, inv_norm, idx, n_tgt, S, D, P, kf0, kf1, st);
-    return wide ? launch_nn<F16, 2>(tgt, piv, inv_norm, idx, n_tgt, S, D, P, kf0, kf1, st)
-                : launch_nn<F16, 1>(tgt, piv, inv_norm, idx, n_tgt, S, D, P, kf0, kf1, st);
+    NnPartial* part = reinterpret_cast<NnPartial*>(ws);
+    return dtype == TF_BF16 ? dispatch_nn<BF16>(tgt, piv, inv_norm, idx, part, n_tgt, S, D, P, kf0, kf1, st)
+                            : dispatch_nn<F16>(tgt, piv, inv_norm, idx, part, n_tgt, S, D, P, kf0, kf1, st);
 }

@@ -28,8 +28,8 @@ def compute_dtype(t: torch.Tensor) -> torch.dtype:
 _ws_cache = {}
 
 
-def _workspace(nbytes: int, device) -> torch.Tensor:
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+def _workspace(nbytes: int, device, tag: str = "attn") -> torch.Tensor:
+    key = (tag, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -98,9 +98,10 @@ def nn_search(tgt: torch.Tensor, piv: torch.Tensor, inv_norm: torch.Tensor, kf_i
     if tgt.dtype != piv.dtype or tgt.shape[1] != D or P not in (1, 2) or any(not 0 <= i < K for i in kf_ids):
         raise ValueError("nn_search: bad arguments")
     idx = torch.empty(P, n_tgt, dtype=torch.int32, device=tgt.device)
+    ws = _workspace(lib.tf_nn_search_workspace_bytes(n_tgt, S, D, P), tgt.device, "nn")
     _lib.check(lib.tf_nn_search(tgt.data_ptr(), piv.data_ptr(), inv_norm.data_ptr(), idx.data_ptr(), n_tgt, S, D, P,
-                                int(kf_ids[0]), int(kf_ids[1]) if P == 2 else 0, _DT[tgt.dtype], _stream()),
-               "tf_nn_search")
+                                int(kf_ids[0]), int(kf_ids[1]) if P == 2 else 0, _DT[tgt.dtype],
+                                ws.data_ptr(), ws.numel(), _stream()), "tf_nn_search")
     return idx
 
 
