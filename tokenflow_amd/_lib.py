@@ -3,7 +3,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtokenflow_hip.so")
+# TOKENFLOW_HIP_LIB overrides the library path (kernel A/B experiments, tools/attn_microbench.py)
+LIB_PATH = os.environ.get("TOKENFLOW_HIP_LIB") or os.path.join(_HERE, "libtokenflow_hip.so")
 
 TF_BF16, TF_F16, TF_F32 = 0, 1, 2
 ABI_VERSION = 1
