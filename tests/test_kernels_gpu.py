@@ -82,7 +82,12 @@ def test_ext_attn_vs_oracle_and_golden(name, dtype, golden_attn):
 
 
 @pytest.mark.parametrize("K,S,h,d", [(2, 256, 2, 40), (3, 136, 2, 64), (2, 200, 1, 80), (1, 16, 2, 160),
-                                     (4, 64, 8, 40), (13, 64, 2, 64)])
+                                     (4, 64, 8, 40), (13, 64, 2, 64),
+                                     # S >= 512 at Dh = 64 takes the ping-pong kernel: one tile, odd / even tile
+                                     # counts, ragged last tile, several keyframes
+                                     (1, 512, 1, 64), (2, 576, 2, 64), (2, 520, 1, 64), (3, 640, 2, 64),
+                                     # S >= 256 at Dh = 40 / 80: 8-wave geometry and the dual (shared-softmax) form
+                                     (2, 328, 2, 40), (2, 264, 1, 80)])
 @pytest.mark.parametrize("inject", [False, True])
 def test_ext_attn_shapes(K, S, h, d, inject):
     """Ragged S (not a multiple of 64 / 128), single keyframe, many heads, K > 12."""

@@ -34,19 +34,21 @@
 
 namespace {
 
-template <int DH>
+template <int DH, int KT>   // KT = keys per staged tile (one barrier interval): 64 or 128
 struct AttnCfg {
     static constexpr int KS = (DH + 15) / 16;   // QK^T k-steps over the head dim
     static constexpr int DKP = KS * 16;         // head dim padded for QK^T (zero columns)
     static constexpr int KROW = DKP + 8;        // K row stride in LDS (elements)
     static constexpr int MT = (DH + 31) / 32;   // PV M-tiles over the head dim
     static constexpr int VROWS = MT * 32;       // V^T rows in LDS (rows >= DH stay constant)
-    static constexpr int VROW = 64 + 8;         // V^T row stride in LDS (elements)
+    static constexpr int VROW = KT + 8;         // V^T row stride in LDS (elements)
     static constexpr int PPR = DH / 8;          // 16-B pieces per K row
-    static constexpr int K_ELEMS = 64 * KROW;
+    static constexpr int VPR = KT / 8;          // 16-B pieces per V^T row
+    static constexpr int SUB = KT / 64;         // 64-key sub-tiles per staged tile
+    static constexpr int K_ELEMS = KT * KROW;
     static constexpr int V_ELEMS = VROWS * VROW;
-    static constexpr int npk(int nt) { return (64 * PPR + nt - 1) / nt; }   // K pieces per thread
-    static constexpr int npv(int nt) { return (DH * 8 + nt - 1) / nt; }     // V^T pieces per thread
+    static constexpr int npk(int nt) { return (KT * PPR + nt - 1) / nt; }   // K pieces per thread
+    static constexpr int npv(int nt) { return (DH * VPR + nt - 1) / nt; }   // V^T pieces per thread
     static constexpr size_t lds_bytes(int nb) { return 2 * (size_t)(K_ELEMS + nb * V_ELEMS) * 2; }
 };
 
@@ -61,6 +63,12 @@ struct AttnParams {
     int64_t ld;
     float c;  // scale * log2(e)
 };
+
+// max over the two lanes (l, l ^ 32) that share a query: v_permlane32_swap instead of an LDS round trip
+__device__ __forceinline__ float max_with_lane_xor32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 
 __device__ __forceinline__ int swap23(int x) { return (x & ~12) | ((x & 4) << 1) | ((x & 8) >> 1); }
 
@@ -99,9 +107,9 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const typename T::elem* __
 //                     (tokenflow_utils.py:124-130), so ONE workgroup computes both: QK^T and the softmax
 //                     once, two P.V products against the two V banks (NB = 2).
 // MINW = min waves per SIMD for the register allocator
-template <typename T, int DH, int QT, int NW, int MODE, int MINW>
+template <typename T, int DH, int QT, int NW, int MODE, int MINW, int KT>
 __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
-    typedef AttnCfg<DH> C;
+    typedef AttnCfg<DH, KT> C;
     typedef typename T::elem E;
     typedef typename T::vec8 vec8;
     typedef typename T::vec4 vec4;
@@ -148,9 +156,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     const int bq = (p.inject && b > 0) ? 0 : b;  // branch whose q and k are used (tokenflow_utils.py:124-130)
     const int f_lo = b == 0 ? p.q_frame0 + f : 0;
     const int n_fr = b == 0 ? 1 : K;
-    const int tpf = (S + 63) >> 6;  // 64-key tiles per frame
+    const int tpf = (S + KT - 1) / KT;  // staged tiles per frame
     const int ntiles = n_fr * tpf;
-    const bool ragged = (S & 63) != 0;
+    const bool ragged = (S % KT) != 0;
 
     const E* qg = reinterpret_cast<const E*>(p.q);
     const E* kg = reinterpret_cast<const E*>(p.k) + ((int64_t)bq * K * S) * p.ld + h * DH;
@@ -163,16 +171,16 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     // ---- LDS pads, written once and never staged over: K columns DH..DKP-1 = 0,
     //      V^T rows DH..VROWS-1 = 0 except row DH = 1 (denominator row) when ONES.
     if constexpr (C::DKP > DH) {
-        for (int id = tid; id < 2 * 64 * (C::DKP - DH); id += NT) {
-            const int bufi = id / (64 * (C::DKP - DH));
-            const int r = (id / (C::DKP - DH)) % 64, cidx = id % (C::DKP - DH);
+        for (int id = tid; id < 2 * KT * (C::DKP - DH); id += NT) {
+            const int bufi = id / (KT * (C::DKP - DH));
+            const int r = (id / (C::DKP - DH)) % KT, cidx = id % (C::DKP - DH);
             sK(bufi)[r * C::KROW + DH + cidx] = (E)0.f;
         }
     }
     if constexpr (C::VROWS > DH) {
-        for (int id = tid; id < 2 * NB * (C::VROWS - DH) * 64; id += NT) {
-            const int bv = id / ((C::VROWS - DH) * 64);
-            const int r = (id >> 6) % (C::VROWS - DH), cidx = id & 63;
+        for (int id = tid; id < 2 * NB * (C::VROWS - DH) * KT; id += NT) {
+            const int bv = id / ((C::VROWS - DH) * KT);
+            const int r = (id / KT) % (C::VROWS - DH), cidx = id % KT;
             sV(bv / NB, bv % NB)[(DH + r) * C::VROW + cidx] = (E)((ONES && r == 0) ? 1.f : 0.f);
         }
     }
@@ -206,48 +214,54 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
         const int id = tid + NT * i;
-        v_goff[i] = (id >> 3) * (int)vt_row + (id & 7) * 8;
-        v_loff[i] = (id >> 3) * C::VROW + (id & 7) * 8;
+        v_goff[i] = (id / C::VPR) * (int)vt_row + (id % C::VPR) * 8;
+        v_loff[i] = (id / C::VPR) * C::VROW + (id % C::VPR) * 8;
     }
-    auto stage_load = [&](int tile) {
-        const int fi = tile / tpf;
-        const int tt = tile - fi * tpf;
-        const int fk = f_lo + fi;
-        const E* kt = kg + ((int64_t)fk * S + tt * 64) * p.ld;
-        if (ragged && tt == tpf - 1) {  // keys past S: clamp the row (masked later), keep the load in bounds
+    // Tile cursors (see ext_attn_pp_kernel): uniform pointer bumps, no division per tile.
+    const int k_wrap = S - (tpf - 1) * KT, v_wrap = p.Spad - (tpf - 1) * KT;
+    const E* k_next = kg + (int64_t)f_lo * S * p.ld;
+    const E* v_next[NB];
+#pragma unroll
+    for (int vb = 0; vb < NB; ++vb) v_next[vb] = vg[vb] + (int64_t)f_lo * p.Spad;
+    int ld_tt = 0;
+    auto stage_load = [&]() {
+        const bool wrap = ld_tt == tpf - 1;
+        if (ragged && wrap) {  // keys past S: clamp the row (masked later), keep the load in bounds
 #pragma unroll
             for (int i = 0; i < NPK; ++i) {
                 const int id = tid + NT * i;
-                if (id < 64 * C::PPR) {
+                if (id < KT * C::PPR) {
                     const int r = id / C::PPR, pc = id - r * C::PPR;
-                    const int key = tt * 64 + r < S ? r : S - 1 - tt * 64;
-                    rk[i] = ld16(kt + (int64_t)key * p.ld + pc * 8);
+                    const int key = r < k_wrap ? r : k_wrap - 1;
+                    rk[i] = ld16(k_next + (int64_t)key * p.ld + pc * 8);
                 }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NPK; ++i)
-                if (tid + NT * i < 64 * C::PPR) rk[i] = ld16(kt + k_goff[i]);
+                if (tid + NT * i < KT * C::PPR) rk[i] = ld16(k_next + k_goff[i]);
         }
 #pragma unroll
         for (int vb = 0; vb < NB; ++vb) {
-            const E* vt = vg[vb] + (int64_t)fk * p.Spad + tt * 64;
 #pragma unroll
             for (int i = 0; i < NPV; ++i)
-                if (tid + NT * i < DH * 8) rv[vb][i] = ld16(vt + v_goff[i]);
+                if (tid + NT * i < DH * C::VPR) rv[vb][i] = ld16(v_next[vb] + v_goff[i]);
+            v_next[vb] += wrap ? v_wrap : KT;
         }
+        k_next += (int64_t)(wrap ? k_wrap : KT) * p.ld;
+        ld_tt = wrap ? 0 : ld_tt + 1;
     };
     auto stage_write = [&](int buf) {
         E* kb = sK(buf);
 #pragma unroll
         for (int i = 0; i < NPK; ++i)
-            if (tid + NT * i < 64 * C::PPR) st16(kb + k_loff[i], rk[i]);
+            if (tid + NT * i < KT * C::PPR) st16(kb + k_loff[i], rk[i]);
 #pragma unroll
         for (int vb = 0; vb < NB; ++vb) {
             E* vbp = sV(buf, vb);
 #pragma unroll
             for (int i = 0; i < NPV; ++i)
-                if (tid + NT * i < DH * 8) st16(vbp + v_loff[i], rv[vb][i]);
+                if (tid + NT * i < DH * C::VPR) st16(vbp + v_loff[i], rv[vb][i]);
         }
     };
 
@@ -267,97 +281,102 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     const float c = p.c;
     const f32x2 c2 = {c, c};
 
-    stage_load(0);
+    stage_load();
     __syncthreads();  // pad fill visible before anything reads; staging regions are disjoint from the pads
     stage_write(0);
     __syncthreads();
 
+    int tt_cur = 0;   // tile index within the frame of the tile being computed
     for (int tile = 0; tile < ntiles; ++tile) {
         const int buf = tile & 1;
         const bool has_next = tile + 1 < ntiles;
-        if (has_next) stage_load(tile + 1);
+        if (has_next) stage_load();
 
-        // Program order per tile: QK(q0) QK(q1) | softmax(q0) PV(q0) | softmax(q1) PV(q1).
-        // MFMAs execute asynchronously behind the in-order issue, so the softmax VALU of one query
-        // tile runs while the matrix pipe works on the other one's QK^T / P.V.
-        f32x16 s[QT][2];  // S^T tiles: 64 keys x 32 queries each
 #pragma unroll
-        for (int qi = 0; qi < QT; ++qi)
+        for (int sub = 0; sub < C::SUB; ++sub) {
+            const int key0 = tt_cur * KT + sub * 64;  // first key (within the frame) of this 64-key sub-tile
+            if (C::SUB > 1 && ragged && key0 >= S) break;   // nothing but padding left in this tile
+            // Program order per tile: QK(q0) QK(q1) | softmax(q0) PV(q0) | softmax(q1) PV(q1).
+            // MFMAs execute asynchronously behind the in-order issue, so the softmax VALU of one query
+            // tile runs while the matrix pipe works on the other one's QK^T / P.V.
+            f32x16 s[QT][2];  // S^T tiles: 64 keys x 32 queries each
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
+            for (int qi = 0; qi < QT; ++qi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[qi][kt][r] = 0.f;
-                const E* krow = sK(buf) + (kt * 32 + l31) * C::KROW + 8 * hi;
+                for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-                for (int t = 0; t < C::KS; ++t)
-                    s[qi][kt] = T::mfma32(__builtin_bit_cast(vec8, ld16(krow + 16 * t)), qf[qi][t], s[qi][kt]);
-            }
-        if (ragged) {
-            const int tt = tile - (tile / tpf) * tpf;
-            if (tt == tpf - 1) {
+                    for (int r = 0; r < 16; ++r) s[qi][kt][r] = 0.f;
+                    const E* krow = sK(buf) + (sub * 64 + kt * 32 + l31) * C::KROW + 8 * hi;
+#pragma unroll
+                    for (int t = 0; t < C::KS; ++t)
+                        s[qi][kt] = T::mfma32(__builtin_bit_cast(vec8, ld16(krow + 16 * t)), qf[qi][t], s[qi][kt]);
+                }
+            if (ragged && key0 + 64 > S) {
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (tt * 64 + kt * 32 + cd_row(r, hi) >= S) {
+                        if (key0 + kt * 32 + cd_row(r, hi) >= S) {
 #pragma unroll
                             for (int qi = 0; qi < QT; ++qi) s[qi][kt][r] = -INFINITY;
                         }
             }
-        }
 
 #pragma unroll
-        for (int qi = 0; qi < QT; ++qi) {
-            // ---- online softmax (lane-local; the two lanes of a query share m)
-            float mx = s[qi][0][0];
+            for (int qi = 0; qi < QT; ++qi) {
+                // ---- online softmax (lane-local; the two lanes of a query share m)
+                float mx = s[qi][0][0];
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qi][kt][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            // rescale only when some query of this wave saw a new maximum: alpha == 1 exactly otherwise
-            if (__any(mx > m_run[qi])) {
-                const float m_new = fmaxf(m_run[qi], mx);
-                const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);  // exp2(-inf) = 0 on tile 0
-                m_run[qi] = m_new;
-                if constexpr (!ONES) l_run[qi] *= alpha;
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qi][kt][r]);
+                mx = max_with_lane_xor32(mx);
+                // rescale only when some query of this wave saw a new maximum: alpha == 1 exactly otherwise
+                if (__any(mx > m_run[qi])) {
+                    const float m_new = fmaxf(m_run[qi], mx);
+                    const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);  // exp2(-inf) = 0 on tile 0
+                    m_run[qi] = m_new;
+                    if constexpr (!ONES) l_run[qi] *= alpha;
+#pragma unroll
+                    for (int vb = 0; vb < NB; ++vb)
+#pragma unroll
+                        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) o[vb][qi][mt][r] *= alpha;
+                }
+                const float mc = m_run[qi] * c;
+                const f32x2 mc2 = {mc, mc};
+                vec8 pf[4];
+                float lsum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 x = f32x2{s[qi][kt][r], s[qi][kt][r + 1]} * c2 - mc2;  // v_pk_fma_f32
+                        const float p0 = __builtin_amdgcn_exp2f(x[0]);
+                        const float p1 = __builtin_amdgcn_exp2f(x[1]);
+                        if constexpr (!ONES) lsum += p0 + p1;
+                        pf[kt * 2 + (r >> 3)][r & 7] = (E)p0;
+                        pf[kt * 2 + (r >> 3)][(r & 7) + 1] = (E)p1;
+                    }
+                if constexpr (!ONES) l_run[qi] += lsum;
+                // ---- O^T += V^T . P  (once per V bank)
 #pragma unroll
                 for (int vb = 0; vb < NB; ++vb)
 #pragma unroll
-                    for (int mt = 0; mt < C::MT; ++mt)
+                    for (int mt = 0; mt < C::MT; ++mt) {
+                        const E* vrow = sV(buf, vb) + (mt * 32 + l31) * C::VROW + sub * 64 + 8 * hi;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) o[vb][qi][mt][r] *= alpha;
+                        for (int ks = 0; ks < 4; ++ks)
+                            o[vb][qi][mt] =
+                                T::mfma32(__builtin_bit_cast(vec8, ld16(vrow + 16 * ks)), pf[ks], o[vb][qi][mt]);
+                    }
             }
-            const float mc = m_run[qi] * c;
-            const f32x2 mc2 = {mc, mc};
-            vec8 pf[4];
-            float lsum = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const f32x2 x = f32x2{s[qi][kt][r], s[qi][kt][r + 1]} * c2 - mc2;  // v_pk_fma_f32
-                    const float p0 = __builtin_amdgcn_exp2f(x[0]);
-                    const float p1 = __builtin_amdgcn_exp2f(x[1]);
-                    if constexpr (!ONES) lsum += p0 + p1;
-                    pf[kt * 2 + (r >> 3)][r & 7] = (E)p0;
-                    pf[kt * 2 + (r >> 3)][(r & 7) + 1] = (E)p1;
-                }
-            if constexpr (!ONES) l_run[qi] += lsum;
-            // ---- O^T += V^T . P  (once per V bank)
-#pragma unroll
-            for (int vb = 0; vb < NB; ++vb)
-#pragma unroll
-                for (int mt = 0; mt < C::MT; ++mt) {
-                    const E* vrow = sV(buf, vb) + (mt * 32 + l31) * C::VROW + 8 * hi;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-                        o[vb][qi][mt] =
-                            T::mfma32(__builtin_bit_cast(vec8, ld16(vrow + 16 * ks)), pf[ks], o[vb][qi][mt]);
-                }
+
         }
 
         if (has_next) stage_write(buf ^ 1);
+        tt_cur = tt_cur == tpf - 1 ? 0 : tt_cur + 1;
         __syncthreads();
     }
 
@@ -392,11 +411,392 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     }
 }
 
-template <typename T, int DH, int QT, int NW, int MODE, int MINW>
+// MFMA issue order of one ping-pong region: round-robin over the independent accumulators
+// (MT P.V chains over 4 k-steps, 2 QK^T chains over KS k-steps).  Two MFMAs on the SAME accumulator with
+// other instructions issued between them cost ~+43 cycles (MI355X_MICROARCH.md, cycle constants), so
+// consecutive steps must always hit different accumulators.
+template <int MT, int KS>
+struct PpSchedule {
+    static constexpr int N = 4 * MT + 2 * KS;
+    int is_pv[N] = {}, chain[N] = {}, kstep[N] = {};
+    constexpr PpSchedule() {
+        int i = 0;
+        for (int r = 0; r < (KS > 4 ? KS : 4); ++r) {
+            for (int mt = 0; mt < MT; ++mt)
+                if (r < 4) {
+                    is_pv[i] = 1;
+                    chain[i] = mt;
+                    kstep[i] = r;
+                    ++i;
+                }
+            for (int kt = 0; kt < 2; ++kt)
+                if (r < KS) {
+                    is_pv[i] = 0;
+                    chain[i] = kt;
+                    kstep[i] = r;
+                    ++i;
+                }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Ping-pong variant (head dims whose registers allow two query tiles per wave: 40, 64).
+//
+// A wave issues in order: a run of back-to-back MFMAs blocks its own VALU until the last one has
+// issued, so softmax and matrix work of ONE query tile can never overlap inside a wave.  Here every
+// wave owns two query tiles, streams A and B, half a tile apart:
+//     R1(t):  exp/round P_A(t)   (VALU)   ||   O_B += V(t-1) P_B(t-1),  S_B(t) = K(t) Q_B     (MFMA)
+//     R2(t):  exp/round P_B(t)   (VALU)   ||   O_A += V(t) P_A(t),      S_A(t+1) = K(t+1) Q_A (MFMA)
+// and inside a region the instruction stream is forced (sched_group_barrier) to alternate
+// 1 MFMA : ~4 VALU/TRANS : 1 LDS fragment read, i.e. the VALU work of one stream rides in the issue
+// gaps of the other stream's MFMAs.  K(t) lives in Kbuf[t&1], V(t) in Vbuf[t&1]; K(t+1) and V(t) are
+// written at the top of R1(t) from registers loaded one iteration earlier; ONE barrier per tile
+// (between R1 and R2) orders all LDS hazards (see the per-line comments).
+template <typename T, int DH, int MODE, int MINW>
+__global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
+    typedef AttnCfg<DH, 64> C;
+    typedef typename T::elem E;
+    typedef typename T::vec8 vec8;
+    typedef typename T::vec4 vec4;
+    constexpr int NT = 256;
+    constexpr int NPK = C::npk(NT), NPV = C::npv(NT);
+    constexpr int BUF_ELEMS = C::K_ELEMS + C::V_ELEMS;
+    constexpr bool ONES = (DH % 32) != 0;
+    constexpr int ONES_R = ((DH % 32) & 3) + 4 * ((DH % 32) >> 3);
+    constexpr int NMFMA = 2 * C::KS + 4 * C::MT;   // MFMAs per region: one QK^T (64 keys) + one P.V
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    auto sK = [&](int buf) { return reinterpret_cast<E*>(smem) + buf * BUF_ELEMS; };
+    auto sV = [&](int buf) { return reinterpret_cast<E*>(smem) + buf * BUF_ELEMS + C::K_ELEMS; };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int hi = lane >> 5;
+    const int l31 = lane & 31;
+    const int K = p.K, Kq = p.Kq, S = p.S, H = p.H;
+
+    const int h = blockIdx.x % H;
+    int u = blockIdx.x / H;
+    int b, f, qt;
+    if constexpr (MODE == MODE_ALL) {
+        const int nbank = 2 * Kq * p.nQT;
+        if (u < nbank) {
+            b = 1 + u / (Kq * p.nQT);
+            u -= (b - 1) * Kq * p.nQT;
+        } else {
+            u -= nbank;
+            b = 0;
+        }
+    } else {
+        b = 0;
+    }
+    f = u / p.nQT;
+    qt = u - f * p.nQT;
+    const int bq = (p.inject && b > 0) ? 0 : b;
+    const int f_lo = b == 0 ? p.q_frame0 + f : 0;
+    const int n_fr = b == 0 ? 1 : K;
+    const int tpf = (S + 63) >> 6;
+    const int ntiles = n_fr * tpf;
+    const bool ragged = (S & 63) != 0;
+
+    const E* qg = reinterpret_cast<const E*>(p.q);
+    const E* kg = reinterpret_cast<const E*>(p.k) + ((int64_t)bq * K * S) * p.ld + h * DH;
+    const int64_t vt_row = (int64_t)K * p.Spad;
+    const E* vg = reinterpret_cast<const E*>(p.vt) + ((int64_t)(b * H + h) * DH) * vt_row;
+
+    // ---- LDS init: everything zero (the pipeline touches Kbuf[1] / Vbuf[1] before they are staged:
+    //      P_B(-1) = 0 times V must not meet NaN bits), then the denominator row of both V^T images.
+    for (int id = tid; id < 2 * BUF_ELEMS / 8; id += NT) st16(reinterpret_cast<E*>(smem) + id * 8, u32x4{0, 0, 0, 0});
+    __syncthreads();
+    if constexpr (ONES)
+        for (int id = tid; id < 2 * 64; id += NT) sV(id >> 6)[DH * C::VROW + (id & 63)] = (E)1.f;
+
+    // ---- Q fragments of both streams
+    int q_row[2];
+    bool q_ok[2];
+    vec8 qf[2][C::KS];
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        q_row[qi] = qt * 256 + (wave * 2 + qi) * 32 + l31;
+        q_ok[qi] = q_row[qi] < S;
+        const E* qp = qg + (((int64_t)bq * Kq + f) * S + (q_ok[qi] ? q_row[qi] : S - 1)) * p.ld + h * DH;
+#pragma unroll
+        for (int t = 0; t < C::KS; ++t) {
+            const int col = 16 * t + 8 * hi;
+            qf[qi][t] = __builtin_bit_cast(vec8, col < DH ? ld16(qp + col) : u32x4{0, 0, 0, 0});
+        }
+    }
+
+    // ---- staging registers: rk = K(t+1), rv = V(t) while iteration t starts
+    u32x4 rk[NPK], rv[NPV];
+    int k_goff[NPK], k_loff[NPK], v_goff[NPV], v_loff[NPV];
+#pragma unroll
+    for (int i = 0; i < NPK; ++i) {
+        const int id = tid + NT * i;
+        const int r = id / C::PPR, pc = id - r * C::PPR;
+        k_goff[i] = r * (int)p.ld + pc * 8;
+        k_loff[i] = r * C::KROW + pc * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+        const int id = tid + NT * i;
+        v_goff[i] = (id >> 3) * (int)vt_row + (id & 7) * 8;
+        v_loff[i] = (id >> 3) * C::VROW + (id & 7) * 8;
+    }
+    // Tile cursors: K rows and V^T positions of consecutive tiles are 64 apart, except at a frame
+    // boundary of a ragged S (the frame's last tile is short in K, padded to Spad in V^T).  Uniform
+    // pointer bumps instead of a tile -> (frame, tile-in-frame) division per load (that SALU sequence,
+    // run by every wave for every tile, measured ~15 % of the kernel).
+    const int k_wrap = S - (tpf - 1) * 64, v_wrap = p.Spad - (tpf - 1) * 64;
+    const E* k_next = kg + (int64_t)f_lo * S * p.ld;   // first row of the next K tile to load
+    const E* v_next = vg + (int64_t)f_lo * p.Spad;
+    int k_tt = 0, v_tt = 0;                            // its tile index within the frame
+    auto load_k = [&]() {
+        if (ragged && k_tt == tpf - 1) {
+#pragma unroll
+            for (int i = 0; i < NPK; ++i) {
+                const int id = tid + NT * i;
+                if (id < 64 * C::PPR) {
+                    const int r = id / C::PPR, pc = id - r * C::PPR;
+                    const int key = r < k_wrap ? r : k_wrap - 1;   // rows past S: clamp (masked later)
+                    rk[i] = ld16(k_next + (int64_t)key * p.ld + pc * 8);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPK; ++i)
+                if (tid + NT * i < 64 * C::PPR) rk[i] = ld16(k_next + k_goff[i]);
+        }
+        const bool wrap = k_tt == tpf - 1;
+        k_next += (int64_t)(wrap ? k_wrap : 64) * p.ld;
+        k_tt = wrap ? 0 : k_tt + 1;
+    };
+    auto load_v = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPV; ++i)
+            if (tid + NT * i < DH * 8) rv[i] = ld16(v_next + v_goff[i]);
+        const bool wrap = v_tt == tpf - 1;
+        v_next += wrap ? v_wrap : 64;
+        v_tt = wrap ? 0 : v_tt + 1;
+    };
+    auto write_k = [&](int buf) {
+        E* kb = sK(buf);
+#pragma unroll
+        for (int i = 0; i < NPK; ++i)
+            if (tid + NT * i < 64 * C::PPR) st16(kb + k_loff[i], rk[i]);
+    };
+    auto write_v = [&](int buf) {
+        E* vb = sV(buf);
+#pragma unroll
+        for (int i = 0; i < NPV; ++i)
+            if (tid + NT * i < DH * 8) st16(vb + v_loff[i], rv[i]);
+    };
+
+    f32x16 o[2][C::MT], s[2][2];
+    vec8 pf[2][4];
+    float m_run[2], l_run[2];
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        m_run[qi] = -INFINITY;
+        l_run[qi] = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qi][mt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[qi][ks][j] = (E)0.f;
+    }
+    const float c = p.c;
+
+    // S^T (64 keys x 32 queries) of stream qi from K buffer `buf`
+    auto qk = [&](auto qi_c, int buf) {
+        constexpr int qi = decltype(qi_c)::value;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[qi][kt][r] = 0.f;
+            const E* krow = sK(buf) + (kt * 32 + l31) * C::KROW + 8 * hi;
+#pragma unroll
+            for (int t = 0; t < C::KS; ++t)
+                s[qi][kt] = T::mfma32(__builtin_bit_cast(vec8, ld16(krow + 16 * t)), qf[qi][t], s[qi][kt]);
+        }
+    };
+    // O^T += V^T . P of stream qi from V buffer `buf`
+    auto pv = [&](auto qi_c, int buf) {
+        constexpr int qi = decltype(qi_c)::value;
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+            const E* vrow = sV(buf) + (mt * 32 + l31) * C::VROW + 8 * hi;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                o[qi][mt] = T::mfma32(__builtin_bit_cast(vec8, ld16(vrow + 16 * ks)), pf[qi][ks], o[qi][mt]);
+        }
+    };
+    // first half of the online softmax: mask, row max, (rare) rescale.  Returns m*c.
+    auto sm_head = [&](auto qi_c, int tile) -> float {
+        constexpr int qi = decltype(qi_c)::value;
+
+        if (ragged) {
+            const int tt = tile - (tile / tpf) * tpf;
+            if (tt == tpf - 1) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (tt * 64 + kt * 32 + cd_row(r, hi) >= S) s[qi][kt][r] = -INFINITY;
+            }
+        }
+        float mx = s[qi][0][0];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qi][kt][r]);
+        mx = max_with_lane_xor32(mx);
+        if (__any(mx > m_run[qi])) {
+            const float m_new = fmaxf(m_run[qi], mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);
+            m_run[qi] = m_new;
+            if constexpr (!ONES) l_run[qi] *= alpha;
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[qi][mt][r] *= alpha;
+        }
+        return m_run[qi] * c;
+    };
+    // One overlapped region: stream X finishes its softmax (P = exp2(s*c - m*c), rounded to the MFMA
+    // input type) on the VALU while stream Y = 1-X runs O_Y += V P_Y (vbuf) and S_Y = K Q_Y (kbuf) on
+    // the matrix pipe.  The region is cut into NMFMA steps, each = { LDS fragment read for step i+2,
+    // MFMA i, its share of the 16 (pk_fma, 2 exp, cvt_pk) softmax units }, and a sched_barrier(0)
+    // after every step pins that order: the wave's in-order issue then alternates matrix and vector work.
+    auto region = [&](auto x_c, float mc, int vbuf, int kbuf) {
+        constexpr int X = decltype(x_c)::value;
+        constexpr int Y = 1 - X;
+        constexpr PpSchedule<C::MT, C::KS> sch{};
+        constexpr int PF = 4;             // fragment reads run PF steps ahead of their MFMA (LDS latency)
+        float lsum = 0.f;
+        const E* vbase = sV(vbuf) + l31 * C::VROW + 8 * hi;
+        const E* kbase = sK(kbuf) + l31 * C::KROW + 8 * hi;
+        auto frag = [&](int i) -> vec8 {
+            if (sch.is_pv[i]) return __builtin_bit_cast(vec8, ld16(vbase + sch.chain[i] * 32 * C::VROW + 16 * sch.kstep[i]));
+            return __builtin_bit_cast(vec8, ld16(kbase + sch.chain[i] * 32 * C::KROW + 16 * sch.kstep[i]));
+        };
+        vec8 fr[NMFMA];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) fr[i] = frag(i);
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NMFMA; ++i) {
+            if (i + PF < NMFMA) fr[i + PF] = frag(i + PF);
+            if (sch.is_pv[i]) {
+                o[Y][sch.chain[i]] = T::mfma32(fr[i], pf[Y][sch.kstep[i]], o[Y][sch.chain[i]]);
+            } else {
+                s[Y][sch.chain[i]] =
+                    T::mfma32(fr[i], qf[Y][sch.kstep[i]], sch.kstep[i] == 0 ? zero : s[Y][sch.chain[i]]);
+            }
+#pragma unroll
+            for (int un = (i * 16) / NMFMA; un < ((i + 1) * 16) / NMFMA; ++un) {
+                const int kt = un >> 3, r = (un & 7) * 2;
+                // two scalar v_fma_f32, NOT one v_pk_fma_f32: packed f32 VALU beside MFMAs costs ~+22 cycles each
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(s[X][kt][r], c, -mc));
+                const float p1 = __builtin_amdgcn_exp2f(fmaf(s[X][kt][r + 1], c, -mc));
+                if constexpr (!ONES) lsum += p0 + p1;
+                pf[X][kt * 2 + (r >> 3)][r & 7] = (E)p0;
+                pf[X][kt * 2 + (r >> 3)][(r & 7) + 1] = (E)p1;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (!ONES) l_run[X] += lsum;
+        // P_X must exist HERE: an empty asm with the registers as read-write operands keeps the compiler
+        // from sinking the (register-only) softmax past the next barrier, next to its consumer
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(pf[X][ks]));
+    };
+    typedef std::integral_constant<int, 0> A;
+    typedef std::integral_constant<int, 1> B;
+
+    // ---- prologue: K(0) -> Kbuf[0]; S_A(0); registers <- K(1), V(0)
+    load_k();                   // K(0)
+    __syncthreads();            // LDS init done before the first staging write
+    write_k(0);
+    if (ntiles > 1) load_k();   // K(1)   (with a single tile rk keeps K(0): written to Kbuf[1], read by a dead S_A(1))
+    load_v();                   // V(0)
+    __syncthreads();
+    qk(A{}, 0);
+
+    int tt = 0;   // tile index of t within its frame
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        // ================= R1(t) =================
+        // Kbuf[nxt] held K(t-1) (last read in R1(t-1)), Vbuf[cur] held V(t-2) (last read in R1(t-1)):
+        // every wave has passed the barrier of iteration t-1, which follows R1(t-1) -> free to overwrite.
+        write_k(nxt);   // K(t+1)
+        write_v(cur);   // V(t)
+        if (t + 2 < ntiles) load_k();   // K(t+2)
+        if (t + 1 < ntiles) load_v();   // V(t+1)
+        // P_A(t) (VALU)  ||  O_B += V(t-1) P_B(t-1) from Vbuf[(t-1)&1],  S_B(t) = K(t) Q_B from Kbuf[t&1] (MFMA)
+        region(A{}, sm_head(A{}, tt), nxt, cur);
+        __syncthreads();   // K(t+1), V(t) visible to all waves; all waves done with R1(t)
+        __builtin_amdgcn_sched_barrier(0);
+        // ================= R2(t) =================
+        // P_B(t) (VALU)  ||  O_A += V(t) P_A(t) from Vbuf[t&1],  S_A(t+1) = K(t+1) Q_A from Kbuf[(t+1)&1]
+        // (a dead tile after the last t) (MFMA)
+        region(B{}, sm_head(B{}, tt), cur, nxt);
+        tt = tt == tpf - 1 ? 0 : tt + 1;
+    }
+    pv(B{}, (ntiles - 1) & 1);         // drain: O_B += V(n-1) P_B(n-1)
+
+    // ---- epilogue
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        float l_tot;
+        if constexpr (ONES)
+            l_tot = __shfl(o[qi][C::MT - 1][ONES_R], l31);
+        else
+            l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32);
+        const float inv_l = 1.0f / l_tot;
+        if (q_ok[qi]) {
+            E* op = reinterpret_cast<E*>(p.out) + (((int64_t)b * Kq + f) * S + q_row[qi]) * ((int64_t)H * DH) + h * DH;
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int d0 = mt * 32 + 8 * rg + 4 * hi;
+                    if (d0 < DH) {
+                        vec4 w;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) w[i] = (E)(o[qi][mt][rg * 4 + i] * inv_l);
+                        *reinterpret_cast<u32x2*>(op + d0) = __builtin_bit_cast(u32x2, w);
+                    }
+                }
+        }
+    }
+}
+
+template <typename T, int DH, int MODE, int MINW>
+int launch_pp(AttnParams p, hipStream_t st) {
+    typedef AttnCfg<DH, 64> C;
+    constexpr size_t lds = C::lds_bytes(1);
+    auto kern = ext_attn_pp_kernel<T, DH, MODE, MINW>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    p.nQT = (p.S + 255) / 256;
+    const int per_branch = p.Kq * p.nQT * p.H;
+    const unsigned grid = (unsigned)(MODE == MODE_ALL ? 3 * per_branch : per_branch);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p);
+    TF_LAUNCH_CHECK("tf_ext_attn_fwd");
+    return 0;
+}
+
+template <typename T, int DH, int QT, int NW, int MODE, int MINW, int KT = 64>
 int launch_one(AttnParams p, hipStream_t st) {
-    typedef AttnCfg<DH> C;
+    typedef AttnCfg<DH, KT> C;
     constexpr size_t lds = C::lds_bytes(MODE == MODE_DUAL ? 2 : 1);
-    auto kern = ext_attn_kernel<T, DH, QT, NW, MODE, MINW>;
+    auto kern = ext_attn_kernel<T, DH, QT, NW, MODE, MINW, KT>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     p.nQT = (p.S + 32 * QT * NW - 1) / (32 * QT * NW);
@@ -435,7 +835,7 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
             const int rc = launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st);
             return rc ? rc : launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st);
         }
-        if (p.S >= 512) return launch_one<T, DH, 2, 4, MODE_ALL, 2>(p, st);
+        if (p.S >= 512) return launch_pp<T, DH, MODE_ALL, 2>(p, st);   // ping-pong: +8..11 % over the plain 2-tile form
         return launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st);
     } else if constexpr (DH == 80) {
         if (p.inject && p.S >= 256) {
@@ -464,7 +864,7 @@ int dispatch_dh(int Dh, const AttnParams& p, const void* v, hipStream_t st) {
 
 extern "C" size_t tf_ext_attn_workspace_bytes(int K, int S, int H, int Dh, int dtype) {
     if (K <= 0 || S <= 0 || H <= 0 || Dh <= 0 || dtype == TF_F32) return 0;
-    const size_t Spad = (size_t)((S + 63) / 64) * 64;
+    const size_t Spad = (size_t)((S + 127) / 128) * 128;   // frames padded to the largest staged tile
     return (size_t)3 * H * Dh * K * Spad * 2;
 }
 
@@ -493,7 +893,7 @@ extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void
     p.q_frame0 = q_frame0;
     p.S = S;
     p.H = H;
-    p.Spad = ((S + 63) / 64) * 64;
+    p.Spad = ((S + 127) / 128) * 128;
     p.nQT = (S + 127) / 128;
     p.inject = inject ? 1 : 0;
     p.ld = ld;
