@@ -100,13 +100,26 @@ def blend_w(n, dev):
     return torch.sigmoid(d2 / (d1 + d2)).to(dev)
 
 
+def usable_cores():
+    """Host cores this process may actually use: CPU affinity capped by the cgroup CPU quota
+    (the GPU box exposes 256 logical CPUs but grants a 16-CPU quota; 256 threads run 4x slower)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(cfg, levels):
     """Time the CPU oracle on a bounded sample and extrapolate to one full step.
     Sample: per level, ONE (frame, head) pair of the bank problem (its queries against the full
     K*S-key bank) and of the source problem, ONE chunk of NN search (two keyframes) and ONE
     chunk of gather/blend; scaled by heads x frames x branches, chunk count and block count."""
     from oracle import tokenflow_oracle as orc
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(usable_cores())
     K, n, C = cfg.K, cfg.chunk, cfg.K
     g = torch.Generator().manual_seed(0)
     total, t_spent, parts = 0.0, 0.0, []

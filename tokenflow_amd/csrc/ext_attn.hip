@@ -823,11 +823,15 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
     }
     if constexpr (DH == 40) {
         if (p.S >= 256) {
+            // 8-wave (256-query) workgroups only while they still give >= 4 workgroups per CU; a frame-sharded
+            // rank with few query frames takes the 4-wave form (twice the workgroups)
+            const bool big = (int64_t)3 * p.Kq * ((p.S + 255) / 256) * p.H >= 1024;
             if (p.inject) {   // 151 VGPRs: 4-wave workgroups, 3 per CU
                 const int rc = launch_one<T, DH, 1, 4, MODE_DUAL, 3>(p, st);
-                return rc ? rc : launch_one<T, DH, 1, 8, MODE_SOURCE, 2>(p, st);
+                if (rc) return rc;
+                return big ? launch_one<T, DH, 1, 8, MODE_SOURCE, 2>(p, st) : launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st);
             }
-            return launch_one<T, DH, 1, 8, MODE_ALL, 2>(p, st);
+            return big ? launch_one<T, DH, 1, 8, MODE_ALL, 2>(p, st) : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st);
         }
         return launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st);
     } else if constexpr (DH == 64) {
