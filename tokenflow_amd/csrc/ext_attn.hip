@@ -2,7 +2,7 @@
 // Replaces tokenflow_utils.py:124-197 / 234-279 of omerbt/TokenFlow: the per-head
 // bmm -> *scale -> softmax -> bmm loops over a K-times replicated key/value bank.
 //
-// Flash-style: one workgroup = 128 queries of one (branch, frame, head); it streams the
+// Flash-style: one workgroup = 128..256 queries of one (branch, frame, head); it streams the
 // key/value sequence (S keys for the source branch, the K*S-key bank of the branch for
 // uncond / cond) in 64-key tiles with an online softmax; nothing of size S x K*S exists.
 // q/k are read in place from the [3,K,S,H*Dh] projection output (head = a Dh-wide column
@@ -19,8 +19,8 @@
 //                   every 16-key group), so P needs NO cross-lane movement at all.
 //   The alpha rescale of O^T is lane-local as well (col = query).
 // V^T comes from a small pre-pass (vt_pack_kernel) that writes the bank transposed,
-// key-permuted and zero-padded per frame to 64 keys into caller-provided scratch
-// (1 read + 1 write of V, <1% of the attention time at the sizes that matter).
+// key-permuted and zero-padded per frame to a multiple of 128 keys into caller-provided scratch
+// (1 read + 1 write of V, ~1.4% of the attention time at the sizes that matter).
 // LDS: double-buffered K [64][DKP+8] and V^T [32*MT][64+8] tiles; the +8 element pad makes
 // every row stride an odd number of 16-B slots -> conflict-free ds_read_b128.
 // Pipeline: tile i+1 is fetched global->registers before the MFMAs of tile i and written
@@ -28,6 +28,11 @@
 // Block order: head = blockIdx % H, so with H = 8 every XCD (block b runs on XCD b % 8)
 // serves one head and its L2 holds only that head's bank; bank problems are queued
 // before the short source problems so the tail of the grid is filled with short work.
+// Three kernels share this structure (geometry table and measurements: DESIGN.md section 4.1):
+//   ext_attn_kernel<.., MODE_ALL / MODE_SOURCE>  the plain form
+//   ext_attn_kernel<.., MODE_DUAL>               q/k injection: uncond + cond share QK^T and the softmax
+//   ext_attn_pp_kernel                           two query tiles per wave, softmax of one interleaved
+//                                                in program order with the MFMAs of the other
 #include <type_traits>
 
 #include "tf_common.h"
