@@ -195,6 +195,32 @@ def test_nn_search_shapes(K, n, S, D):
         _nn_check(tgt, piv, bi, f"S{S} D{D} chunk{bi}")
 
 
+def test_nn_search_f16():
+    """f16 inputs (the reference's own autocast dtype) take the f16 MFMA path."""
+    ops = _ops()
+    K, n, S, D = 2, 3, 160, 320
+    g = torch.Generator().manual_seed(21)
+    ln = torch.nn.LayerNorm(D, elementwise_affine=False)
+    piv = ln(torch.randn(K, S, D, generator=g)).half().float()
+    tgt = (piv[1][torch.randperm(S, generator=g)][None].repeat(n, 1, 1) + 0.1 * torch.randn(n, S, D, generator=g)).half().float()
+    ref_idx, sim = orc.nn_search(tgt, piv, 1)
+    dp = piv.half().cuda()
+    got = ops.nn_search(tgt.reshape(-1, D).half().cuda(), dp, ops.pivot_inv_norm(dp), [1, 0]).cpu()
+    for p_, (r, s_) in enumerate(zip(ref_idx, sim.chunk(2, dim=1))):
+        _, bad = orc.nn_mismatch_tie_aware(s_, r, got[p_], NN_TAU)
+        assert bad == 0
+
+
+def test_nn_search_argument_errors():
+    ops = _ops()
+    from tokenflow_amd._lib import TokenflowHipError
+    piv = torch.zeros(2, 16, 36, dtype=torch.bfloat16, device="cuda")       # D = 36 is not a multiple of 8
+    with pytest.raises(TokenflowHipError, match="tf_nn_search"):
+        ops.nn_search(piv[0], piv, torch.ones(2, 16, device="cuda"), [0])
+    with pytest.raises(ValueError):
+        ops.nn_search(piv[0], piv, torch.ones(2, 16, device="cuda"), [2])   # keyframe index out of range
+
+
 def test_nn_search_exact_ties_first_index():
     """Duplicate pivot rows give bit-identical scores: the FIRST index must win (torch.argmax)."""
     ops = _ops()
