@@ -207,18 +207,24 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     }
 
     // ---- staging: per-thread piece offsets are loop-invariant; a tile only moves uniform base pointers
+    // The loads are branch-free (one straight-line path, no exec masking): a lane without a piece re-loads
+    // the last piece, a row past S is clamped by a select.  Any control flow around the loads makes the
+    // compiler merge the two definitions of the staging registers with v_mov copies, and those copies
+    // need the data: an s_waitcnt vmcnt(0) right behind the loads that exposes the full L2 latency on
+    // every tile (measured ~0.8 ms of a 4.2 ms launch).
     u32x4 rk[NPK], rv[NB][NPV];
-    int k_goff[NPK], k_loff[NPK], v_goff[NPV], v_loff[NPV];
+    int k_row[NPK], k_col[NPK], k_goff[NPK], k_loff[NPK], v_goff[NPV], v_loff[NPV];
 #pragma unroll
     for (int i = 0; i < NPK; ++i) {
-        const int id = tid + NT * i;
-        const int r = id / C::PPR, pc = id - r * C::PPR;
-        k_goff[i] = r * (int)p.ld + pc * 8;
-        k_loff[i] = r * C::KROW + pc * 8;
+        const int id = min(tid + NT * i, KT * C::PPR - 1);
+        k_row[i] = id / C::PPR;
+        k_col[i] = (id - k_row[i] * C::PPR) * 8;
+        k_goff[i] = k_row[i] * (int)p.ld + k_col[i];
+        k_loff[i] = k_row[i] * C::KROW + k_col[i];
     }
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
-        const int id = tid + NT * i;
+        const int id = min(tid + NT * i, DH * C::VPR - 1);
         v_goff[i] = (id / C::VPR) * (int)vt_row + (id % C::VPR) * 8;
         v_loff[i] = (id / C::VPR) * C::VROW + (id % C::VPR) * 8;
     }
@@ -231,26 +237,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     int ld_tt = 0;
     auto stage_load = [&]() {
         const bool wrap = ld_tt == tpf - 1;
-        if (ragged && wrap) {  // keys past S: clamp the row (masked later), keep the load in bounds
+        const int rlim = wrap ? k_wrap - 1 : KT - 1;   // last valid key row of this tile (rows past S are masked later)
+        const int clamp_off = rlim * (int)p.ld;
 #pragma unroll
-            for (int i = 0; i < NPK; ++i) {
-                const int id = tid + NT * i;
-                if (id < KT * C::PPR) {
-                    const int r = id / C::PPR, pc = id - r * C::PPR;
-                    const int key = r < k_wrap ? r : k_wrap - 1;
-                    rk[i] = ld16(k_next + (int64_t)key * p.ld + pc * 8);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NPK; ++i)
-                if (tid + NT * i < KT * C::PPR) rk[i] = ld16(k_next + k_goff[i]);
-        }
+        for (int i = 0; i < NPK; ++i) rk[i] = ld16(k_next + (k_row[i] <= rlim ? k_goff[i] : clamp_off + k_col[i]));
 #pragma unroll
         for (int vb = 0; vb < NB; ++vb) {
 #pragma unroll
-            for (int i = 0; i < NPV; ++i)
-                if (tid + NT * i < DH * C::VPR) rv[vb][i] = ld16(v_next[vb] + v_goff[i]);
+            for (int i = 0; i < NPV; ++i) rv[vb][i] = ld16(v_next[vb] + v_goff[i]);
             v_next[vb] += wrap ? v_wrap : KT;
         }
         k_next += (int64_t)(wrap ? k_wrap : KT) * p.ld;
@@ -535,53 +529,42 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
     }
 
     // ---- staging registers: rk = K(t+1), rv = V(t) while iteration t starts
+    // (loads branch-free for the reason given in ext_attn_kernel)
     u32x4 rk[NPK], rv[NPV];
-    int k_goff[NPK], k_loff[NPK], v_goff[NPV], v_loff[NPV];
+    int k_row[NPK], k_col[NPK], k_goff[NPK], k_loff[NPK], v_goff[NPV], v_loff[NPV];
 #pragma unroll
     for (int i = 0; i < NPK; ++i) {
-        const int id = tid + NT * i;
-        const int r = id / C::PPR, pc = id - r * C::PPR;
-        k_goff[i] = r * (int)p.ld + pc * 8;
-        k_loff[i] = r * C::KROW + pc * 8;
+        const int id = min(tid + NT * i, 64 * C::PPR - 1);
+        k_row[i] = id / C::PPR;
+        k_col[i] = (id - k_row[i] * C::PPR) * 8;
+        k_goff[i] = k_row[i] * (int)p.ld + k_col[i];
+        k_loff[i] = k_row[i] * C::KROW + k_col[i];
     }
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
-        const int id = tid + NT * i;
+        const int id = min(tid + NT * i, DH * 8 - 1);
         v_goff[i] = (id >> 3) * (int)vt_row + (id & 7) * 8;
         v_loff[i] = (id >> 3) * C::VROW + (id & 7) * 8;
     }
     // Tile cursors: K rows and V^T positions of consecutive tiles are 64 apart, except at a frame
     // boundary of a ragged S (the frame's last tile is short in K, padded to Spad in V^T).  Uniform
-    // pointer bumps instead of a tile -> (frame, tile-in-frame) division per load (that SALU sequence,
-    // run by every wave for every tile, measured ~15 % of the kernel).
+    // pointer bumps instead of a tile -> (frame, tile-in-frame) division per load.
     const int k_wrap = S - (tpf - 1) * 64, v_wrap = p.Spad - (tpf - 1) * 64;
     const E* k_next = kg + (int64_t)f_lo * S * p.ld;   // first row of the next K tile to load
     const E* v_next = vg + (int64_t)f_lo * p.Spad;
     int k_tt = 0, v_tt = 0;                            // its tile index within the frame
     auto load_k = [&]() {
-        if (ragged && k_tt == tpf - 1) {
-#pragma unroll
-            for (int i = 0; i < NPK; ++i) {
-                const int id = tid + NT * i;
-                if (id < 64 * C::PPR) {
-                    const int r = id / C::PPR, pc = id - r * C::PPR;
-                    const int key = r < k_wrap ? r : k_wrap - 1;   // rows past S: clamp (masked later)
-                    rk[i] = ld16(k_next + (int64_t)key * p.ld + pc * 8);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NPK; ++i)
-                if (tid + NT * i < 64 * C::PPR) rk[i] = ld16(k_next + k_goff[i]);
-        }
         const bool wrap = k_tt == tpf - 1;
+        const int rlim = wrap ? k_wrap - 1 : 63;
+        const int clamp_off = rlim * (int)p.ld;
+#pragma unroll
+        for (int i = 0; i < NPK; ++i) rk[i] = ld16(k_next + (k_row[i] <= rlim ? k_goff[i] : clamp_off + k_col[i]));
         k_next += (int64_t)(wrap ? k_wrap : 64) * p.ld;
         k_tt = wrap ? 0 : k_tt + 1;
     };
     auto load_v = [&]() {
 #pragma unroll
-        for (int i = 0; i < NPV; ++i)
-            if (tid + NT * i < DH * 8) rv[i] = ld16(v_next + v_goff[i]);
+        for (int i = 0; i < NPV; ++i) rv[i] = ld16(v_next + v_goff[i]);
         const bool wrap = v_tt == tpf - 1;
         v_next += wrap ? v_wrap : 64;
         v_tt = wrap ? 0 : v_tt + 1;
