@@ -75,9 +75,14 @@ __device__ __forceinline__ float max_with_lane_xor32(float x) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// Row stride (elements) of the V^T scratch: K*Spad positions + 64 elements of padding.  K*Spad*2 bytes is a
+// large power of two at the BASELINE shapes (64 KiB at cfg2 level 0); the rows d = 0..Dh-1 of one V^T tile
+// would then all map to the same memory channel and the tile loads serialise.  The 128-byte skew spreads them.
+__host__ __device__ __forceinline__ int64_t vt_row_stride(int K, int Spad) { return (int64_t)K * Spad + 64; }
+
 __device__ __forceinline__ int swap23(int x) { return (x & ~12) | ((x & 4) << 1) | ((x & 8) >> 1); }
 
-// V [3,K,S,H*DH] (token stride ld) -> Vt [3][H][DH][K*Spad], position = f*Spad + swap23(key in frame),
+// V [3,K,S,H*DH] (token stride ld) -> Vt [3][H][DH][K*Spad + 64], position = f*Spad + swap23(key in frame),
 // zero for keys >= S.  grid = (Spad/64, H, 3*K), 256 threads.
 template <typename T>
 __global__ __launch_bounds__(256) void vt_pack_kernel(const typename T::elem* __restrict__ v,
@@ -96,10 +101,11 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const typename T::elem* __
         tile[key * row + d] = kk < S ? src[(int64_t)kk * ld + d] : (E)0.f;
     }
     __syncthreads();
-    E* dst = vt + ((int64_t)(b * H + h) * DH) * ((int64_t)K * Spad) + (int64_t)f * Spad + tt * 64;
+    const int64_t vt_row = vt_row_stride(K, Spad);
+    E* dst = vt + ((int64_t)(b * H + h) * DH) * vt_row + (int64_t)f * Spad + tt * 64;
     for (int id = threadIdx.x; id < 64 * DH; id += 256) {
         const int d = id >> 6, pos = id & 63;
-        dst[(int64_t)d * ((int64_t)K * Spad) + pos] = tile[swap23(pos) * row + d];
+        dst[(int64_t)d * vt_row + pos] = tile[swap23(pos) * row + d];
     }
 }
 
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
 
     const E* qg = reinterpret_cast<const E*>(p.q);
     const E* kg = reinterpret_cast<const E*>(p.k) + ((int64_t)bq * K * S) * p.ld + h * DH;
-    const int64_t vt_row = (int64_t)K * p.Spad;
+    const int64_t vt_row = vt_row_stride(K, p.Spad);
     const E* vg[NB];
 #pragma unroll
     for (int vb = 0; vb < NB; ++vb)
@@ -502,7 +508,7 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
 
     const E* qg = reinterpret_cast<const E*>(p.q);
     const E* kg = reinterpret_cast<const E*>(p.k) + ((int64_t)bq * K * S) * p.ld + h * DH;
-    const int64_t vt_row = (int64_t)K * p.Spad;
+    const int64_t vt_row = vt_row_stride(K, p.Spad);
     const E* vg = reinterpret_cast<const E*>(p.vt) + ((int64_t)(b * H + h) * DH) * vt_row;
 
     // ---- LDS init: everything zero (the pipeline touches Kbuf[1] / Vbuf[1] before they are staged:
@@ -857,7 +863,7 @@ int dispatch_dh(int Dh, const AttnParams& p, const void* v, hipStream_t st) {
 extern "C" size_t tf_ext_attn_workspace_bytes(int K, int S, int H, int Dh, int dtype) {
     if (K <= 0 || S <= 0 || H <= 0 || Dh <= 0 || dtype == TF_F32) return 0;
     const size_t Spad = (size_t)((S + 127) / 128) * 128;   // frames padded to the largest staged tile
-    return (size_t)3 * H * Dh * K * Spad * 2;
+    return (size_t)3 * H * Dh * (size_t)vt_row_stride(K, (int)Spad) * 2;
 }
 
 extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void* out, int K, int Kq, int q_frame0,
