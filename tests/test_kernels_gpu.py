@@ -9,6 +9,9 @@ Tolerances (stated here, used below):
     ATTN_ATOL = 2e-4 (fp32 accumulation order, v_exp_f32), EPS = 2^-8 (bf16 relative half-ulp:
     8 significand bits; 2^-11 for f16).  Second term = rounding of the output itself, third = worst case of rounding each
     probability before P.V (what the reference's autocast path does too).
+    At Dh = 40 the kernel additionally rounds q*scale*log2(e) to 16 bit once (softmax scale folded into
+    the QK^T MFMA): a per-element relative error <= 2^-9 on q, i.e. a score perturbation of the same
+    size class as the P rounding, covered by the same third term.
     At BASELINE shapes (thousands of keys, |out| <~ 0.25) the third term averages out and the
     bound is the north-star's "< 1e-3"; tests/test_fullsize_gpu.py asserts that number directly.
   * NN indices: equal, or the oracle's fp32 similarity of the two candidates differs by

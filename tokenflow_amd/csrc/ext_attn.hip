@@ -134,6 +134,17 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     constexpr bool ONES = (DH % 32) != 0;
     constexpr int ONES_R = ((DH % 32) & 3) + 4 * ((DH % 32) >> 3);  // C/D register of row DH%32 (lane half 0)
     static_assert(!ONES || ((DH % 32) & 4) == 0, "row DH must live in lane half 0");
+    // FOLD (head dims with spare QK^T columns, i.e. Dh = 40): the softmax's scale AND shift ride in the MFMA.
+    //   * Q fragments hold q * (scale*log2 e), rounded to the MFMA input type once per kernel;
+    //   * the first pad column of the K image (column Dh) is 1.0 and the matching pad element of the Q
+    //     fragment holds -shift, so the accumulator comes out as  s*c - shift  and P = exp2(acc) directly:
+    //     no v_fma per score (32 of ~87 VALU instructions per 32x64 tile; the kernel is VALU-issue bound).
+    //   The shift is a per-query running value, representable in the input type, moved only when a tile's
+    //   maximum exceeds it by more than FOLD_T (and always on the first tile); softmax is invariant to the
+    //   shift, numerator and denominator see the same P, so no accuracy is traded for the deferral.
+    constexpr bool FOLD = ONES && (C::DKP > DH);
+    constexpr int SH_T = DH / 16, SH_HI = (DH % 16) / 8;   // k-step and lane half that hold column Dh
+    constexpr float FOLD_T = 8.0f;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     auto sK = [&](int buf) { return reinterpret_cast<E*>(smem) + buf * BUF_ELEMS; };
@@ -185,7 +196,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
         for (int id = tid; id < 2 * KT * (C::DKP - DH); id += NT) {
             const int bufi = id / (KT * (C::DKP - DH));
             const int r = (id / (C::DKP - DH)) % KT, cidx = id % (C::DKP - DH);
-            sK(bufi)[r * C::KROW + DH + cidx] = (E)0.f;
+            sK(bufi)[r * C::KROW + DH + cidx] = (E)((FOLD && cidx == 0) ? 1.f : 0.f);
         }
     }
     if constexpr (C::VROWS > DH) {
@@ -209,6 +220,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
         for (int t = 0; t < C::KS; ++t) {
             const int col = 16 * t + 8 * hi;
             qf[qi][t] = __builtin_bit_cast(vec8, col < DH ? ld16(qp + col) : u32x4{0, 0, 0, 0});
+            if constexpr (FOLD) {   // q * (scale*log2 e), rounded once to the MFMA input type
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[qi][t][j] = (E)((float)qf[qi][t][j] * p.c);
+            }
         }
     }
 
@@ -274,7 +289,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     float m_run[QT], l_run[QT];  // running max of the RAW scores (scale > 0); this lane's share of the denominator
 #pragma unroll
     for (int qi = 0; qi < QT; ++qi) {
-        m_run[qi] = -INFINITY;
+        m_run[qi] = FOLD ? 0.f : -INFINITY;   // FOLD: the current shift
         l_run[qi] = 0.f;
 #pragma unroll
         for (int vb = 0; vb < NB; ++vb)
@@ -336,35 +351,64 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qi][kt][r]);
                 mx = max_with_lane_xor32(mx);
-                // rescale only when some query of this wave saw a new maximum: alpha == 1 exactly otherwise
-                if (__any(mx > m_run[qi])) {
-                    const float m_new = fmaxf(m_run[qi], mx);
-                    const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);  // exp2(-inf) = 0 on tile 0
-                    m_run[qi] = m_new;
-                    if constexpr (!ONES) l_run[qi] *= alpha;
-#pragma unroll
-                    for (int vb = 0; vb < NB; ++vb)
-#pragma unroll
-                        for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) o[vb][qi][mt][r] *= alpha;
-                }
-                const float mc = m_run[qi] * c;
-                const f32x2 mc2 = {mc, mc};
                 vec8 pf[4];
-                float lsum = 0.f;
+                if constexpr (FOLD) {
+                    // s already is  score*c - shift.  Move the shift only when needed (wave-uniform branch).
+                    const bool first = tile == 0 && sub == 0;
+                    float delta = 0.f;
+                    if (first || __any(mx > FOLD_T)) {
+                        const float sh_old = m_run[qi];          // m_run holds the current shift (0 before tile 0)
+                        const float sh_new = (first || mx > FOLD_T) ? (float)(E)(sh_old + mx) : sh_old;
+                        delta = sh_new - sh_old;
+                        const float alpha = __builtin_amdgcn_exp2f(-delta);
+                        m_run[qi] = sh_new;
+                        if (hi == SH_HI) qf[qi][SH_T][0] = (E)(-sh_new);
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
+                        for (int vb = 0; vb < NB; ++vb)
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const f32x2 x = f32x2{s[qi][kt][r], s[qi][kt][r + 1]} * c2 - mc2;  // v_pk_fma_f32
-                        const float p0 = __builtin_amdgcn_exp2f(x[0]);
-                        const float p1 = __builtin_amdgcn_exp2f(x[1]);
-                        if constexpr (!ONES) lsum += p0 + p1;
-                        pf[kt * 2 + (r >> 3)][r & 7] = (E)p0;
-                        pf[kt * 2 + (r >> 3)][(r & 7) + 1] = (E)p1;
+                            for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) o[vb][qi][mt][r] *= alpha;
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) s[qi][kt][r] -= delta;
                     }
-                if constexpr (!ONES) l_run[qi] += lsum;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            pf[kt * 2 + (r >> 3)][r & 7] = (E)__builtin_amdgcn_exp2f(s[qi][kt][r]);
+                } else {
+                    // rescale only when some query of this wave saw a new maximum: alpha == 1 exactly otherwise
+                    if (__any(mx > m_run[qi])) {
+                        const float m_new = fmaxf(m_run[qi], mx);
+                        const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);  // exp2(-inf) = 0 on tile 0
+                        m_run[qi] = m_new;
+                        if constexpr (!ONES) l_run[qi] *= alpha;
+#pragma unroll
+                        for (int vb = 0; vb < NB; ++vb)
+#pragma unroll
+                            for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) o[vb][qi][mt][r] *= alpha;
+                    }
+                    const float mc = m_run[qi] * c;
+                    const f32x2 mc2 = {mc, mc};
+                    float lsum = 0.f;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) {
+                            const f32x2 x = f32x2{s[qi][kt][r], s[qi][kt][r + 1]} * c2 - mc2;  // v_pk_fma_f32
+                            const float p0 = __builtin_amdgcn_exp2f(x[0]);
+                            const float p1 = __builtin_amdgcn_exp2f(x[1]);
+                            if constexpr (!ONES) lsum += p0 + p1;
+                            pf[kt * 2 + (r >> 3)][r & 7] = (E)p0;
+                            pf[kt * 2 + (r >> 3)][(r & 7) + 1] = (E)p1;
+                        }
+                    if constexpr (!ONES) l_run[qi] += lsum;
+                }
                 // ---- O^T += V^T . P  (once per V bank)
 #pragma unroll
                 for (int vb = 0; vb < NB; ++vb)
