@@ -514,6 +514,10 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
     constexpr bool ONES = (DH % 32) != 0;
     constexpr int ONES_R = ((DH % 32) & 3) + 4 * ((DH % 32) >> 3);
     constexpr int NMFMA = 2 * C::KS + 4 * C::MT;   // MFMAs per region: one QK^T (64 keys) + one P.V
+    // softmax scale and shift folded into the QK^T MFMA (see ext_attn_kernel)
+    constexpr bool FOLD = ONES && (C::DKP > DH);
+    constexpr int SH_T = DH / 16, SH_HI = (DH % 16) / 8;
+    constexpr float FOLD_T = 8.0f;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     auto sK = [&](int buf) { return reinterpret_cast<E*>(smem) + buf * BUF_ELEMS; };
@@ -561,6 +565,8 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
     __syncthreads();
     if constexpr (ONES)
         for (int id = tid; id < 2 * 64; id += NT) sV(id >> 6)[DH * C::VROW + (id & 63)] = (E)1.f;
+    if constexpr (FOLD)
+        for (int id = tid; id < 2 * 64; id += NT) sK(id >> 6)[(id & 63) * C::KROW + DH] = (E)1.f;
 
     // ---- Q fragments of both streams
     int q_row[2];
@@ -575,6 +581,10 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
         for (int t = 0; t < C::KS; ++t) {
             const int col = 16 * t + 8 * hi;
             qf[qi][t] = __builtin_bit_cast(vec8, col < DH ? ld16(qp + col) : u32x4{0, 0, 0, 0});
+            if constexpr (FOLD) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[qi][t][j] = (E)((float)qf[qi][t][j] * p.c);
+            }
         }
     }
 
@@ -637,7 +647,7 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
     float m_run[2], l_run[2];
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
-        m_run[qi] = -INFINITY;
+        m_run[qi] = FOLD ? 0.f : -INFINITY;   // FOLD: the current shift
         l_run[qi] = 0.f;
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt)
@@ -675,7 +685,7 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
         }
     };
     // first half of the online softmax: mask, row max, (rare) rescale.  Returns m*c.
-    auto sm_head = [&](auto qi_c, int tile) -> float {
+    auto sm_head = [&](auto qi_c, int tile, bool first) -> float {   // tile = index within the frame
         constexpr int qi = decltype(qi_c)::value;
 
         if (ragged) {
@@ -694,6 +704,27 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qi][kt][r]);
         mx = max_with_lane_xor32(mx);
+        if constexpr (FOLD) {
+            // s already is score*c - shift: move the shift only on the first tile or when the tile maximum
+            // exceeds it by more than FOLD_T (wave-uniform branch)
+            if (first || __any(mx > FOLD_T)) {
+                const float sh_old = m_run[qi];
+                const float sh_new = (first || mx > FOLD_T) ? (float)(E)(sh_old + mx) : sh_old;
+                const float delta = sh_new - sh_old;
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                m_run[qi] = sh_new;
+                if (hi == SH_HI) qf[qi][SH_T][0] = (E)(-sh_new);
+#pragma unroll
+                for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[qi][mt][r] *= alpha;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[qi][kt][r] -= delta;
+            }
+            return 0.f;
+        }
         if (__any(mx > m_run[qi])) {
             const float m_new = fmaxf(m_run[qi], mx);
             const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);
@@ -740,8 +771,8 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
             for (int un = (i * 16) / NMFMA; un < ((i + 1) * 16) / NMFMA; ++un) {
                 const int kt = un >> 3, r = (un & 7) * 2;
                 // two scalar v_fma_f32, NOT one v_pk_fma_f32: packed f32 VALU beside MFMAs costs ~+22 cycles each
-                const float p0 = __builtin_amdgcn_exp2f(fmaf(s[X][kt][r], c, -mc));
-                const float p1 = __builtin_amdgcn_exp2f(fmaf(s[X][kt][r + 1], c, -mc));
+                const float p0 = __builtin_amdgcn_exp2f(FOLD ? s[X][kt][r] : fmaf(s[X][kt][r], c, -mc));
+                const float p1 = __builtin_amdgcn_exp2f(FOLD ? s[X][kt][r + 1] : fmaf(s[X][kt][r + 1], c, -mc));
                 if constexpr (!ONES) lsum += p0 + p1;
                 pf[X][kt * 2 + (r >> 3)][r & 7] = (E)p0;
                 pf[X][kt * 2 + (r >> 3)][(r & 7) + 1] = (E)p1;
@@ -777,13 +808,13 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
         if (t + 2 < ntiles) load_k();   // K(t+2)
         if (t + 1 < ntiles) load_v();   // V(t+1)
         // P_A(t) (VALU)  ||  O_B += V(t-1) P_B(t-1) from Vbuf[(t-1)&1],  S_B(t) = K(t) Q_B from Kbuf[t&1] (MFMA)
-        region(A{}, sm_head(A{}, tt), nxt, cur);
+        region(A{}, sm_head(A{}, tt, t == 0), nxt, cur);
         __syncthreads();   // K(t+1), V(t) visible to all waves; all waves done with R1(t)
         __builtin_amdgcn_sched_barrier(0);
         // ================= R2(t) =================
         // P_B(t) (VALU)  ||  O_A += V(t) P_A(t) from Vbuf[t&1],  S_A(t+1) = K(t+1) Q_A from Kbuf[(t+1)&1]
         // (a dead tile after the last t) (MFMA)
-        region(B{}, sm_head(B{}, tt), cur, nxt);
+        region(B{}, sm_head(B{}, tt, t == 0), cur, nxt);
         tt = tt == tpf - 1 ? 0 : tt + 1;
     }
     pv(B{}, (ntiles - 1) & 1);         // drain: O_B += V(n-1) P_B(n-1)
