@@ -37,6 +37,10 @@ extern "C" {
 #define TF_F16 1
 #define TF_F32 2
 
+/* tf_ext_attn_fwd flags (the `inject` argument is a bit mask) */
+#define TF_ATTN_INJECT 1       /* q/k injection: uncond and cond use the source branch's q and k */
+#define TF_ATTN_EXACT_SCALE 2  /* scale the scores in fp32 (no folding of scale*log2e into q) */
+
 /* argument errors */
 #define TF_ERR_NULL (-1)
 #define TF_ERR_DTYPE (-2)
@@ -64,8 +68,11 @@ const char* tf_last_error(void);
  *   source branch: frame f attends to its own S keys (lines 173,177);
  *   uncond / cond: frame f attends to all K*S keys of its branch (133-138,
  *   174-179) -- the bank is read in place, never replicated.
- *   inject != 0: uncond and cond use the SOURCE branch's q and k (124-130),
+ *   inject & TF_ATTN_INJECT: uncond and cond use the SOURCE branch's q and k (124-130),
  *   by pointer aliasing; q and k are not modified.
+ *   inject & TF_ATTN_EXACT_SCALE: at Dh = 40 the kernel by default folds scale*log2(e) into q (rounded
+ *   to the input dtype once, relative error <= 2^-9 per element; +12 % speed); this flag keeps the
+ *   reference's fp32 scaling of the scores.  No effect at other head dims.
  *   scale = attn.scale (Dh^-0.5).  Dh in {40, 64, 80, 160}; dtype bf16 or f16;
  *   S, ld multiples of 8.  fp32 softmax / accumulation, online softmax over
  *   64-key tiles, P rounded to the input dtype before P.V (as the reference's

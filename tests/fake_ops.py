@@ -23,7 +23,7 @@ class FakeOps:
     def compute_dtype(self, t):
         return t.dtype
 
-    def ext_attn(self, q, k, v, heads, scale, inject, out=None, q_frame0=0):
+    def ext_attn(self, q, k, v, heads, scale, inject, out=None, q_frame0=0, exact_scale=None):
         self.calls.append(("ext_attn", tuple(q.shape), bool(inject)))
         K, Kq = k.shape[0] // 3, q.shape[0] // 3
         qf = self._r(q)

@@ -64,7 +64,7 @@ struct AttnParams {
     const void* k;
     const void* vt;
     void* out;
-    int K, Kq, q_frame0, S, H, Spad, nQT, inject;  // K bank frames; queries = frames q_frame0 .. +Kq
+    int K, Kq, q_frame0, S, H, Spad, nQT, inject, exact_scale;  // K bank frames; queries = frames q_frame0 .. +Kq
     int64_t ld;
     float c;  // scale * log2(e)
 };
@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const typename T::elem* __
 //                     (tokenflow_utils.py:124-130), so ONE workgroup computes both: QK^T and the softmax
 //                     once, two P.V products against the two V banks (NB = 2).
 // MINW = min waves per SIMD for the register allocator
-template <typename T, int DH, int QT, int NW, int MODE, int MINW, int KT>
+// FQ   = fold the softmax scale into Q (see FOLD below); false = exact fp32 scaling of the scores
+template <typename T, int DH, int QT, int NW, int MODE, int MINW, int KT, bool FQ>
 __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     typedef AttnCfg<DH, KT> C;
     typedef typename T::elem E;
@@ -142,7 +143,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     //   The shift is a per-query running value, representable in the input type, moved only when a tile's
     //   maximum exceeds it by more than FOLD_T (and always on the first tile); softmax is invariant to the
     //   shift, numerator and denominator see the same P, so no accuracy is traded for the deferral.
-    constexpr bool FOLD = ONES && (C::DKP > DH);
+    //   What IS traded: q*c is rounded to 16 bit once, a relative error <= 2^-9 per element that perturbs each
+    //   score by ~2^-9/sqrt(3) * c * sqrt(sum_d (q_d k_d)^2) -- the size class of the P rounding for ordinary
+    //   scores, larger for very peaked softmaxes (|score| >> 1).  TF_ATTN_EXACT_SCALE selects the fp32 scaling.
+    constexpr bool FOLD = FQ && ONES && (C::DKP > DH);
     constexpr int SH_T = DH / 16, SH_HI = (DH % 16) / 8;   // k-step and lane half that hold column Dh
     constexpr float FOLD_T = 8.0f;
 
@@ -861,11 +865,11 @@ int launch_pp(AttnParams p, hipStream_t st) {
     return 0;
 }
 
-template <typename T, int DH, int QT, int NW, int MODE, int MINW, int KT = 64>
+template <typename T, int DH, int QT, int NW, int MODE, int MINW, bool FQ = true, int KT = 64>
 int launch_one(AttnParams p, hipStream_t st) {
     typedef AttnCfg<DH, KT> C;
     constexpr size_t lds = C::lds_bytes(MODE == MODE_DUAL ? 2 : 1);
-    auto kern = ext_attn_kernel<T, DH, QT, NW, MODE, MINW, KT>;
+    auto kern = ext_attn_kernel<T, DH, QT, NW, MODE, MINW, KT, FQ>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     p.nQT = (p.S + 32 * QT * NW - 1) / (32 * QT * NW);
@@ -895,6 +899,16 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
             // 8-wave (256-query) workgroups only while they still give >= 4 workgroups per CU; a frame-sharded
             // rank with few query frames takes the 4-wave form (twice the workgroups)
             const bool big = (int64_t)3 * p.Kq * ((p.S + 255) / 256) * p.H >= 1024;
+            if (p.exact_scale) {   // fp32 score scaling (TF_ATTN_EXACT_SCALE)
+                if (p.inject) {
+                    const int rc = launch_one<T, DH, 1, 4, MODE_DUAL, 3, false>(p, st);
+                    if (rc) return rc;
+                    return big ? launch_one<T, DH, 1, 8, MODE_SOURCE, 2, false>(p, st)
+                               : launch_one<T, DH, 1, 4, MODE_SOURCE, 2, false>(p, st);
+                }
+                return big ? launch_one<T, DH, 1, 8, MODE_ALL, 2, false>(p, st)
+                           : launch_one<T, DH, 1, 4, MODE_ALL, 2, false>(p, st);
+            }
             if (p.inject) {   // 151 VGPRs: 4-wave workgroups, 3 per CU
                 const int rc = launch_one<T, DH, 1, 4, MODE_DUAL, 3>(p, st);
                 if (rc) return rc;
@@ -902,6 +916,7 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
             }
             return big ? launch_one<T, DH, 1, 8, MODE_ALL, 2>(p, st) : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st);
         }
+        if (p.exact_scale) return launch_one<T, DH, 1, 4, MODE_ALL, 2, false>(p, st);
         return launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st);
     } else if constexpr (DH == 64) {
         if (p.inject && p.S >= 256) {
@@ -968,7 +983,8 @@ extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void
     p.H = H;
     p.Spad = ((S + 127) / 128) * 128;
     p.nQT = (S + 127) / 128;
-    p.inject = inject ? 1 : 0;
+    p.inject = (inject & TF_ATTN_INJECT) ? 1 : 0;
+    p.exact_scale = (inject & TF_ATTN_EXACT_SCALE) ? 1 : 0;
     p.ld = ld;
     p.c = (float)((double)scale * 1.4426950408889634);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

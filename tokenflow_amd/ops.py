@@ -1,5 +1,6 @@
 """Torch-tensor wrappers over the C ABI.  PyTorch supplies device memory and the
 current HIP stream; all arithmetic happens in the HIP kernels.  No fallbacks."""
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -37,8 +38,13 @@ def _workspace(nbytes: int, device, tag: str = "attn") -> torch.Tensor:
     return ws
 
 
+# TOKENFLOW_EXACT_SCALE=1: fp32 scaling of the attention scores at head dim 40 (default: scale folded into q)
+EXACT_SCALE = os.environ.get("TOKENFLOW_EXACT_SCALE", "0") not in ("", "0")
+
+
 def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float,
-             inject: bool, out: Optional[torch.Tensor] = None, q_frame0: int = 0) -> torch.Tensor:
+             inject: bool, out: Optional[torch.Tensor] = None, q_frame0: int = 0,
+             exact_scale: Optional[bool] = None) -> torch.Tensor:
     """Extended attention core (tokenflow_utils.py:124-197).  k,v: [3K,S,D] bf16/f16 (the bank),
     q: [3Kq,S,D] = the queries of keyframes q_frame0..q_frame0+Kq-1 (Kq = K on one GPU); last dim
     contiguous, equal token stride.  Returns [3Kq,S,D] in the same dtype."""
@@ -64,11 +70,12 @@ def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scal
         ld = D
     if out is None:
         out = torch.empty(Bq, S, D, dtype=q.dtype, device=q.device)
+    flags = (1 if inject else 0) | (2 if (EXACT_SCALE if exact_scale is None else exact_scale) else 0)
     nbytes = lib.tf_ext_attn_workspace_bytes(K, S, heads, dh, dt)
     ws = _workspace(nbytes, q.device)
     _lib.check(lib.tf_ext_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), K, Kq, int(q_frame0),
                                    S, heads, dh,
-                                   ld, float(scale), int(bool(inject)), dt, ws.data_ptr(), ws.numel(), _stream()),
+                                   ld, float(scale), flags, dt, ws.data_ptr(), ws.numel(), _stream()),
                "tf_ext_attn_fwd")
     return out
 
