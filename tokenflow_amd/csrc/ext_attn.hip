@@ -83,29 +83,40 @@ __host__ __device__ __forceinline__ int64_t vt_row_stride(int K, int Spad) { ret
 __device__ __forceinline__ int swap23(int x) { return (x & ~12) | ((x & 4) << 1) | ((x & 8) >> 1); }
 
 // V [3,K,S,H*DH] (token stride ld) -> Vt [3][H][DH][K*Spad + 64], position = f*Spad + swap23(key in frame),
-// zero for keys >= S.  grid = (Spad/64, H, 3*K), 256 threads.
+// zero for keys >= S.  grid = (Spad/64, H, 3*K), 256 threads; one workgroup = 64 keys x DH of one head.
+// 16-byte global accesses on both sides (rows of V in, 8 consecutive positions of one V^T row out); the
+// transpose itself is 2-byte LDS reads of a [64][DH+2] tile (odd dword stride: conflict-free columns).
 template <typename T>
 __global__ __launch_bounds__(256) void vt_pack_kernel(const typename T::elem* __restrict__ v,
                                                       typename T::elem* __restrict__ vt, int K, int S, int H, int DH,
                                                       int Spad, int64_t ld) {
     typedef typename T::elem E;
+    typedef typename T::vec8 vec8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     E* tile = reinterpret_cast<E*>(smem);  // [64][DH + 2]
     const int row = DH + 2;
+    const int ppr = DH >> 3;               // 16-B pieces per V row
     const int tt = blockIdx.x, h = blockIdx.y, bf = blockIdx.z;  // bf = b*K + f
     const int b = bf / K, f = bf - b * K;
     const E* src = v + ((int64_t)bf * S) * ld + h * DH;
-    for (int id = threadIdx.x; id < 64 * DH; id += 256) {
-        const int key = id / DH, d = id - key * DH;
+    for (int id = threadIdx.x; id < 64 * ppr; id += 256) {
+        const int key = id / ppr, pc = id - key * ppr;
         const int kk = tt * 64 + key;
-        tile[key * row + d] = kk < S ? src[(int64_t)kk * ld + d] : (E)0.f;
+        const vec8 val = kk < S ? __builtin_bit_cast(vec8, ld16(src + (int64_t)kk * ld + pc * 8))
+                                : __builtin_bit_cast(vec8, u32x4{0, 0, 0, 0});
+        E* dstp = tile + key * row + pc * 8;   // (DH+2)*2 bytes per row: only 4-byte aligned -> element stores
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dstp[j] = val[j];
     }
     __syncthreads();
     const int64_t vt_row = vt_row_stride(K, Spad);
     E* dst = vt + ((int64_t)(b * H + h) * DH) * vt_row + (int64_t)f * Spad + tt * 64;
-    for (int id = threadIdx.x; id < 64 * DH; id += 256) {
-        const int d = id >> 6, pos = id & 63;
-        dst[(int64_t)d * vt_row + pos] = tile[swap23(pos) * row + d];
+    for (int id = threadIdx.x; id < DH * 8; id += 256) {
+        const int d = id >> 3, pg = id & 7;   // 8 consecutive positions pg*8 .. +7 of V^T row d
+        vec8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = tile[swap23(pg * 8 + j) * row + d];
+        st16(dst + (int64_t)d * vt_row + pg * 8, __builtin_bit_cast(u32x4, o));
     }
 }
 
