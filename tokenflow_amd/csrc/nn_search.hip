@@ -33,10 +33,12 @@ struct NnPartial {
 };
 
 constexpr int TM = 128;  // pivots per tile
-constexpr int BK = 64;   // D chunk
-
-__device__ __forceinline__ int swz_off(int row, int piece) {  // byte offset in a [rows][64] 16-bit tile
-    return row * 128 + ((piece ^ ((row >> 1) & 7)) << 4);
+// byte offset of 16-B piece `piece` of row `row` in a [rows][BK] 16-bit tile, BK = 64 or 128 (D chunk).
+// 128-B rows: two rows share a 256-B bank row -> XOR by (row >> 1) & 7; 256-B rows: XOR by row & 15.
+template <int BK>
+__device__ __forceinline__ int swz_off(int row, int piece) {
+    if constexpr (BK == 64) return row * 128 + ((piece ^ ((row >> 1) & 7)) << 4);
+    return row * 256 + ((piece ^ (row & 15)) << 4);
 }
 
 // ---------------------------------------------------------------------------
@@ -68,7 +70,9 @@ __global__ __launch_bounds__(256) void pivot_inv_norm_kernel(const typename T::e
 
 // ---------------------------------------------------------------------------
 // WN = 32-target sub-tiles per wave (1 or 2): workgroup covers TN = 64*WN targets.
-template <typename T, int WN>
+// BK = D chunk per barrier interval: 64, or 128 for small problems (few workgroups, where the per-iteration
+//      global-load latency is exposed: halving the iteration count halves the run time).
+template <typename T, int WN, int BK>
 __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* __restrict__ tgt,
                                                         const typename T::elem* __restrict__ piv,
                                                         const float* __restrict__ inv_norm,
@@ -77,10 +81,11 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
                                                         int D, int kf0, int kf1, int tiles_per_split) {
     typedef typename T::vec8 vec8;
     constexpr int TN = 64 * WN;
-    constexpr int A_BYTES = TM * 128;
-    constexpr int B_BYTES = TN * 128;
-    constexpr int NPA = TM * 8 / 256;  // 16-B pieces per thread, A chunk
-    constexpr int NPB = TN * 8 / 256;
+    constexpr int PPR = BK / 8;              // 16-B pieces per chunk row
+    constexpr int A_BYTES = TM * BK * 2;
+    constexpr int B_BYTES = TN * BK * 2;
+    constexpr int NPA = TM * PPR / 256;      // 16-B pieces per thread, A chunk
+    constexpr int NPB = TN * PPR / 256;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     auto sA = [&](int b) { return smem + b * (A_BYTES + B_BYTES); };
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
     const int n_kc = (D + BK - 1) / BK;
     const int total = n_mt * n_kc;
 
-    // per-thread staging pieces: piece id = tid + 256*i -> row = id >> 3, col piece = id & 7
+    // per-thread staging pieces: piece id = tid + 256*i -> row = id / PPR, col piece = id % PPR
     u32x4 ra[NPA], rb[NPB];
     float rinv = 0.f;
 
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
             const int id = tid + 256 * i;
-            const int r = id >> 3, pc = id & 7;
+            const int r = id / PPR, pc = id % PPR;
             int row = (mt0 + mt) * TM + r;
             row = row < S ? row : S - 1;  // clamped duplicates can never win (see epilogue)
             const int col = col0 + pc * 8;
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
 #pragma unroll
         for (int i = 0; i < NPB; ++i) {
             const int id = tid + 256 * i;
-            const int r = id >> 3, pc = id & 7;
+            const int r = id / PPR, pc = id % PPR;
             int64_t row = t0 + r;
             row = row < n_tgt ? row : n_tgt - 1;
             const int col = col0 + pc * 8;
@@ -146,12 +151,12 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
             const int id = tid + 256 * i;
-            st16(sA(b) + swz_off(id >> 3, id & 7), ra[i]);
+            st16(sA(b) + swz_off<BK>(id / PPR, id % PPR), ra[i]);
         }
 #pragma unroll
         for (int i = 0; i < NPB; ++i) {
             const int id = tid + 256 * i;
-            st16(sB(b) + swz_off(id >> 3, id & 7), rb[i]);
+            st16(sB(b) + swz_off<BK>(id / PPR, id % PPR), rb[i]);
         }
         if (kc == 0 && tid < TM) sInv[(mt & 1) * TM + tid] = rinv;
     };
@@ -184,14 +189,14 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
         const unsigned char* a = sA(it & 1);
         const unsigned char* b = sB(it & 1);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < BK / 16; ++ks) {
             vec8 fa[2], fb[WN];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                fa[i] = __builtin_bit_cast(vec8, ld16(a + swz_off(wr * 64 + i * 32 + l31, ks * 2 + hi)));
+                fa[i] = __builtin_bit_cast(vec8, ld16(a + swz_off<BK>(wr * 64 + i * 32 + l31, ks * 2 + hi)));
 #pragma unroll
             for (int j = 0; j < WN; ++j)
-                fb[j] = __builtin_bit_cast(vec8, ld16(b + swz_off((wc * WN + j) * 32 + l31, ks * 2 + hi)));
+                fb[j] = __builtin_bit_cast(vec8, ld16(b + swz_off<BK>((wc * WN + j) * 32 + l31, ks * 2 + hi)));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -417,15 +422,15 @@ static int finalize(const NnPartial* part, int32_t* idx, int64_t total, int spli
     return 0;
 }
 
-template <typename T, int WN>
+template <typename T, int WN, int BK>
 int launch_nn(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, NnPartial* ws, int64_t n_tgt,
               int S, int D, int P, int kf0, int kf1, hipStream_t st) {
     constexpr int TN = 64 * WN;
-    const size_t lds = 2 * (TM * 128 + TN * 128) + 2 * TM * 4 + 2 * TN * 8;
+    const size_t lds = 2 * (TM + TN) * BK * 2 + 2 * TM * 4 + 2 * TN * 8;
     const NnPlan pl = nn_plan(n_tgt, S, D, P);
     const int splits = pl.splits, tps = pl.tiles_per_split;
     dim3 grid((unsigned)pl.panels, (unsigned)P, (unsigned)splits);
-    auto kern = nn_search_kernel<T, WN>;
+    auto kern = nn_search_kernel<T, WN, BK>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, reinterpret_cast<const typename T::elem*>(tgt),
                        reinterpret_cast<const typename T::elem*>(piv), inv_norm, idx, splits > 1 ? ws : nullptr, n_tgt,
@@ -455,8 +460,11 @@ int dispatch_nn(const void* tgt, const void* piv, const float* inv_norm, int32_t
     const NnPlan pl = nn_plan(n_tgt, S, D, P);
     if (pl.rb) return launch_nn_rb<T, 20>(tgt, piv, inv_norm, idx, ws, n_tgt, S, P, kf0, kf1, st);
     // 128-target panels when they still give >= 2 workgroups per CU, else 64-target panels
-    return pl.wide ? launch_nn<T, 2>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st)
-                : launch_nn<T, 1>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st);
+    if (pl.wide) return launch_nn<T, 2, 64>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st);
+    // few workgroups and a long contraction: latency-bound per iteration -> 128-wide D chunks
+    if (pl.panels * P * pl.splits <= 512 && D >= 512)
+        return launch_nn<T, 1, 128>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st);
+    return launch_nn<T, 1, 64>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st);
 }
 
 }  // namespace
