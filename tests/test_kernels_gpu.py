@@ -169,6 +169,31 @@ def test_ext_attn_softmax_spike(d):
     assert_attn_close(out_ex, refs, f"spike d={d} exact_scale", folded=False)
 
 
+@pytest.mark.parametrize("gain", [3.0, 12.0])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("d", [40, 80])
+def test_ext_attn_folded_shift_paths(d, dtype, gain):
+    """The folded-softmax kernels (Dh = 40; Dh = 80 always looks) skip the per-tile maximum while |q'| max|k| - shift stays under a
+    threshold (2^60 headroom in bf16, 2^8 in f16).  gain = 3: the bound holds in bf16, the scores climb
+    ~25 binades above the first tile's shift without any rescale; gain = 12: the bound fails, so the
+    kernel looks at every tile's maximum and moves the shift in late tiles.  Both in both dtypes, on a
+    2-frame bank with a ragged last tile."""
+    ops = _ops()
+    K, S, h = 2, 200, 2
+    g = torch.Generator().manual_seed(17)
+    q, k, v = (torch.randn(3 * K, S, h * d, generator=g) for _ in range(3))
+    for b in range(3 * K):
+        for s in range(0, S, 5):
+            k[b, (s * 3 + 140) % S] = q[b, s] * gain
+    rnd = orc.bf16_round if dtype == torch.bfloat16 else (lambda x: x.half().float())
+    q, k, v = (rnd(x) for x in (q, k, v))
+    for inject in (False, True):
+        refs = attn_ref(q, k, v, h, d ** -0.5, inject)
+        out = ops.ext_attn(q.to(dtype).cuda(), k.to(dtype).cuda(), v.to(dtype).cuda(), h, d ** -0.5, inject)
+        assert torch.isfinite(out.float()).all()
+        assert_attn_close(out, refs, f"shift paths d={d} {dtype} gain={gain} inject={inject}", dtype=dtype, folded=True)
+
+
 def test_ext_attn_argument_errors():
     ops = _ops()
     from tokenflow_amd._lib import TokenflowHipError

@@ -63,6 +63,7 @@ struct AttnParams {
     const void* q;
     const void* k;
     const void* vt;
+    const float* knorm2;  // [3][H][K*Spad/64] max |k|^2 per 64-key block, FOLD kernels only (from vt_pack_kernel)
     void* out;
     int K, Kq, q_frame0, S, H, Spad, nQT, inject, exact_scale;  // K bank frames; queries = frames q_frame0 .. +Kq
     int64_t ld;
@@ -80,16 +81,24 @@ __device__ __forceinline__ float max_with_lane_xor32(float x) {
 // would then all map to the same memory channel and the tile loads serialise.  The 128-byte skew spreads them.
 __host__ __device__ __forceinline__ int64_t vt_row_stride(int K, int Spad) { return (int64_t)K * Spad + 64; }
 
+static inline size_t vt_bytes(int K, int Spad, int H, int Dh) {
+    return (size_t)3 * H * Dh * (size_t)vt_row_stride(K, Spad) * 2;
+}
+
 __device__ __forceinline__ int swap23(int x) { return (x & ~12) | ((x & 4) << 1) | ((x & 8) >> 1); }
 
 // V [3,K,S,H*DH] (token stride ld) -> Vt [3][H][DH][K*Spad + 64], position = f*Spad + swap23(key in frame),
 // zero for keys >= S.  grid = (Spad/64, H, 3*K), 256 threads; one workgroup = 64 keys x DH of one head.
 // 16-byte global accesses on both sides (rows of V in, 8 consecutive positions of one V^T row out); the
 // transpose itself is 2-byte LDS reads of a [64][DH+2] tile (odd dword stride: conflict-free columns).
+// With k != nullptr (FOLD kernels) the same workgroup also writes max |k|^2 over its 64 keys of this head to
+// knorm2[(b*H + h) * K*Spad/64 + f*Spad/64 + tt]: the score bound q.k <= |q| max|k| of ext_attn_kernel.
 template <typename T>
 __global__ __launch_bounds__(256) void vt_pack_kernel(const typename T::elem* __restrict__ v,
-                                                      typename T::elem* __restrict__ vt, int K, int S, int H, int DH,
-                                                      int Spad, int64_t ld) {
+                                                      typename T::elem* __restrict__ vt,
+                                                      const typename T::elem* __restrict__ k,
+                                                      float* __restrict__ knorm2, int k_branches, int K, int S,
+                                                      int H, int DH, int Spad, int64_t ld) {
     typedef typename T::elem E;
     typedef typename T::vec8 vec8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -99,6 +108,21 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const typename T::elem* __
     const int tt = blockIdx.x, h = blockIdx.y, bf = blockIdx.z;  // bf = b*K + f
     const int b = bf / K, f = bf - b * K;
     const E* src = v + ((int64_t)bf * S) * ld + h * DH;
+    if (k != nullptr && b < k_branches && threadIdx.x < 64) {   // wave 0: one key per lane
+        const int kk = tt * 64 + (int)threadIdx.x;
+        float acc = 0.f;
+        if (kk < S) {
+            const E* kp = k + ((int64_t)bf * S + kk) * ld + h * DH;
+            for (int c8 = 0; c8 < DH; c8 += 8) {
+                const vec8 x = __builtin_bit_cast(vec8, ld16(kp + c8));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc = fmaf((float)x[j], (float)x[j], acc);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc = fmaxf(acc, __shfl_xor(acc, o));
+        if (threadIdx.x == 0) knorm2[((int64_t)(b * H + h) * K + f) * (Spad / 64) + tt] = acc;
+    }
     for (int id = threadIdx.x; id < 64 * ppr; id += 256) {
         const int key = id / ppr, pc = id - key * ppr;
         const int kk = tt * 64 + key;
@@ -159,7 +183,15 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     //   scores, larger for very peaked softmaxes (|score| >> 1).  TF_ATTN_EXACT_SCALE selects the fp32 scaling.
     constexpr bool FOLD = FQ && ONES && (C::DKP > DH);
     constexpr int SH_T = DH / 16, SH_HI = (DH % 16) / 8;   // k-step and lane half that hold column Dh
-    constexpr float FOLD_T = 8.0f;
+    //   Most tiles never look at their maximum: |acc + shift| = |q'.k| <= |q'| max_k|k| (Cauchy-Schwarz; the
+    //   key norm bound comes with the vt_pack_kernel pre-pass), so while  |q'| |k|max - shift <= FOLD_T  no
+    //   score of any tile can exceed the threshold and the max3 chain + permlane (16 of ~66 VALU per tile)
+    //   is skipped; a query whose bound is loose falls back to the per-tile maximum.  exp2 of FOLD_T must
+    //   stay far inside the input type's range with room for the row sum: 2^60 for bf16, 2^8 for f16.
+    //   Measured (MI355X, cfg2): -6.5 % on the Dh = 40 kernel; nothing at Dh = 80, whose tile is MFMA-heavier
+    //   (the extra K read of the pre-pass then costs more than it saves), so the bound is used at Dh = 40 only.
+    constexpr float FOLD_T = std::is_same<E, _Float16>::value ? 8.0f : 60.0f;
+    constexpr bool BOUND = FOLD && DH == 40;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     auto sK = [&](int buf) { return reinterpret_cast<E*>(smem) + buf * BUF_ELEMS; };
@@ -239,6 +271,26 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) qf[qi][t][j] = (E)((float)qf[qi][t][j] * p.c);
             }
+        }
+    }
+    float s_bound[QT] = {};   // FOLD: upper bound of q'.k over every key of the bank (1e-3 covers the fp32 rounding)
+    if constexpr (BOUND) {
+        const int ppf = p.Spad / 64;   // 64-key blocks per frame; this problem sees frames f_lo .. f_lo + n_fr - 1
+        const float* part = p.knorm2 + ((int64_t)(bq * H + h) * K + f_lo) * ppf;
+        float kn2 = 0.f;
+        for (int i = lane; i < n_fr * ppf; i += 64) kn2 = fmaxf(kn2, part[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) kn2 = fmaxf(kn2, __shfl_xor(kn2, o));
+        const float kn = __builtin_sqrtf(kn2) * 1.001f;
+#pragma unroll
+        for (int qi = 0; qi < QT; ++qi) {
+            float q2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < C::KS; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) q2 = fmaf((float)qf[qi][t][j], (float)qf[qi][t][j], q2);
+            q2 += __shfl_xor(q2, 32);   // the two lanes of a query hold disjoint halves of its columns
+            s_bound[qi] = __builtin_sqrtf(q2) * kn;
         }
     }
 
@@ -360,18 +412,23 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
 #pragma unroll
             for (int qi = 0; qi < QT; ++qi) {
                 // ---- online softmax (lane-local; the two lanes of a query share m)
-                float mx = s[qi][0][0];
+                auto tile_max = [&]() {
+                    float mx = s[qi][0][0];
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
+                    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qi][kt][r]);
-                mx = max_with_lane_xor32(mx);
+                        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qi][kt][r]);
+                    return max_with_lane_xor32(mx);
+                };
                 vec8 pf[4];
                 if constexpr (FOLD) {
-                    // s already is  score*c - shift.  Move the shift only when needed (wave-uniform branch).
+                    // s already is  score*c - shift.  Move the shift only when needed (wave-uniform branches).
                     const bool first = tile == 0 && sub == 0;
                     float delta = 0.f;
-                    if (first || __any(mx > FOLD_T)) {
+                    float mx = 0.f;
+                    const bool look = !BOUND || first || __any(s_bound[qi] - m_run[qi] > FOLD_T);
+                    if (look) mx = tile_max();
+                    if (look && (first || __any(mx > FOLD_T))) {
                         const float sh_old = m_run[qi];          // m_run holds the current shift (0 before tile 0)
                         const float sh_new = (first || mx > FOLD_T) ? (float)(E)(sh_old + mx) : sh_old;
                         delta = sh_new - sh_old;
@@ -395,6 +452,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
                         for (int r = 0; r < 16; ++r)
                             pf[kt * 2 + (r >> 3)][r & 7] = (E)__builtin_amdgcn_exp2f(s[qi][kt][r]);
                 } else {
+                    const float mx = tile_max();
                     // rescale only when some query of this wave saw a new maximum: alpha == 1 exactly otherwise
                     if (__any(mx > m_run[qi])) {
                         const float m_new = fmaxf(m_run[qi], mx);
@@ -901,8 +959,12 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
     {   // pre-pass: V -> transposed, key-permuted, per-frame padded bank
         dim3 grid((unsigned)(p.Spad / 64), (unsigned)p.H, (unsigned)(3 * p.K));
         const size_t lds = (size_t)64 * (DH + 2) * sizeof(E);
+        // the folded-softmax kernels of Dh = 40 also need the key norm bounds (branch 0 only under injection)
+        const bool fold = DH == 40 && !p.exact_scale;
         hipLaunchKernelGGL(vt_pack_kernel<T>, grid, dim3(256), lds, st, reinterpret_cast<const E*>(v),
-                           reinterpret_cast<E*>(const_cast<void*>(p.vt)), p.K, p.S, p.H, DH, p.Spad, p.ld);
+                           reinterpret_cast<E*>(const_cast<void*>(p.vt)),
+                           fold ? reinterpret_cast<const E*>(p.k) : nullptr, const_cast<float*>(p.knorm2),
+                           p.inject ? 1 : 3, p.K, p.S, p.H, DH, p.Spad, p.ld);
         TF_LAUNCH_CHECK("tf_ext_attn_fwd(vt_pack)");
     }
     if constexpr (DH == 40) {
@@ -964,7 +1026,7 @@ int dispatch_dh(int Dh, const AttnParams& p, const void* v, hipStream_t st) {
 extern "C" size_t tf_ext_attn_workspace_bytes(int K, int S, int H, int Dh, int dtype) {
     if (K <= 0 || S <= 0 || H <= 0 || Dh <= 0 || dtype == TF_F32) return 0;
     const size_t Spad = (size_t)((S + 127) / 128) * 128;   // frames padded to the largest staged tile
-    return (size_t)3 * H * Dh * (size_t)vt_row_stride(K, (int)Spad) * 2;
+    return ((vt_bytes(K, (int)Spad, H, Dh) + 255) & ~(size_t)255) + (size_t)3 * H * K * (Spad / 64) * sizeof(float);   // V^T image | key norm bounds
 }
 
 extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void* out, int K, int Kq, int q_frame0,
@@ -986,6 +1048,8 @@ extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void
     p.q = q;
     p.k = k;
     p.vt = ws;
+    p.knorm2 = reinterpret_cast<const float*>(static_cast<const unsigned char*>(ws) +
+                                              ((vt_bytes(K, ((S + 127) / 128) * 128, H, Dh) + 255) & ~(size_t)255));
     p.out = out;
     p.K = K;
     p.Kq = Kq;
