@@ -15,7 +15,8 @@ injection is on for every other step (the reference injects during the first 50 
 timesteps, config_pnp.yaml:21).
 
 N > 1: frames are sharded over ranks (tokenflow_amd/sharded.py): the SAME video is split,
-so scaling is "strong"; the bank all-gather and the neighbour halo exchange run through
+so scaling is "strong"; the pivotal-pass exchange (frames <-> heads all-to-all, or the bank
+all-gather with --pivotal-exchange bank) and the neighbour halo exchange run through
 torch.distributed (RCCL) inside the timed region.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the head-dim-40
@@ -45,6 +46,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg2", choices=list(workload.CONFIGS))
+    ap.add_argument("--pivotal-exchange", default="auto", choices=["auto", "heads", "bank"],
+                    help="N > 1: how the pivotal pass is exchanged (sharded.py); auto = heads when they divide")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N > 1: nccl (= RCCL); gloo lets several ranks share one GPU on a development box "
+                         "(functional check of the N > 1 path, its timing means nothing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-levels", default="0,1,2,3")
     return ap.parse_args()
@@ -74,7 +80,7 @@ class Block:
         self.attn_flops = workload.attn_flops(cfg.K, S, D) * Kl / cfg.K
 
 
-def run_step(cfg, blocks, shard, inject_on, w, events=None):
+def run_step(cfg, blocks, shard, inject_on, w, events=None, exchange=None):
     n = cfg.chunk
     for blk in blocks:
         inj = inject_on and blk.injected and cfg.pnp
@@ -84,7 +90,7 @@ def run_step(cfg, blocks, shard, inject_on, w, events=None):
         if shard.world == 1:
             kf_out = ops.ext_attn(blk.q, blk.k, blk.v, blk.h, (blk.D // blk.h) ** -0.5, inj)
         else:
-            kf_out = shard.pivotal_attention(blk.q, blk.k, blk.v, blk.h, (blk.D // blk.h) ** -0.5, inj)
+            kf_out = shard.pivotal_attention(blk.q, blk.k, blk.v, blk.h, (blk.D // blk.h) ** -0.5, inj, mode=exchange)
         if events is not None and blk.lvl == 0:
             e1.record()
             events.append((e0, e1, blk.attn_flops))
@@ -174,16 +180,25 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     cfg = workload.CONFIGS[args.config]
     shard = sharded.FrameShard(cfg.K)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     blocks = [Block(cfg, lvl, inj, shard, gen, dev) for lvl, inj in workload.BLOCKS]
     w = blend_w(cfg.chunk, dev)
+    exchange = None if args.pivotal_exchange == "auto" else args.pivotal_exchange
+    heads_ok = all(l[2] % world == 0 for l in cfg.levels)
+    exch_name = {"heads": "frames<->heads all-to-all", "bank": "K/V bank all-gather"}[
+        exchange or ("heads" if heads_ok else "bank")]
 
     def barrier():
         if world > 1:
@@ -191,12 +206,12 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        run_step(cfg, blocks, shard, i % 2 == 0, w)
+        run_step(cfg, blocks, shard, i % 2 == 0, w, exchange=exchange)
     events = []
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        run_step(cfg, blocks, shard, i % 2 == 0, w, events)
+        run_step(cfg, blocks, shard, i % 2 == 0, w, events, exchange=exchange)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -227,7 +242,8 @@ def main():
         "config": {"workload": cfg.name + " (hot path: 16 blocks x [ext-attn + %d x (NN-search + gather/blend)])" % cfg.K,
                    "frames": cfg.frames, "keyframes": cfg.K, "frames_per_chunk": cfg.chunk,
                    "levels_S_D_heads": [list(l) for l in cfg.levels],
-                   "parallelism": "frames sharded over %d GPU(s)" % world,
+                   "parallelism": "1 GPU" if world == 1 else
+                   "frames sharded over %d GPUs; pivotal pass: %s" % (world, exch_name),
                    "step_algorithmic_tflop": round((fa + fn) / 1e12, 2),
                    "step_tflops_achieved": round((fa + fn) / 1e12 / (ms_per_step * 1e-3), 1)},
         "roofline": {"kernel": "ext_attn_kernel<bf16, Dh=%d> level 0 (+ V^T pre-pass inside the event bracket)"

@@ -40,6 +40,8 @@ extern "C" {
 /* tf_ext_attn_fwd flags (the `inject` argument is a bit mask) */
 #define TF_ATTN_INJECT 1       /* q/k injection: uncond and cond use the source branch's q and k */
 #define TF_ATTN_EXACT_SCALE 2  /* scale the scores in fp32 (no folding of scale*log2e into q) */
+#define TF_ATTN_BANK_ONLY 4    /* compute only the uncond and cond branches (those that read the K-frame bank) */
+#define TF_ATTN_SOURCE_ONLY 8  /* compute only the source branch (own-frame keys) */
 
 /* argument errors */
 #define TF_ERR_NULL (-1)

@@ -23,18 +23,36 @@ class FakeOps:
     def compute_dtype(self, t):
         return t.dtype
 
-    def ext_attn(self, q, k, v, heads, scale, inject, out=None, q_frame0=0, exact_scale=None):
-        self.calls.append(("ext_attn", tuple(q.shape), bool(inject)))
+    def ext_attn(self, q, k, v, heads, scale, inject, out=None, q_frame0=0, exact_scale=None, part="all"):
+        self.calls.append(("ext_attn", tuple(q.shape), bool(inject)) + ((part,) if part != "all" else ()))
         K, Kq = k.shape[0] // 3, q.shape[0] // 3
-        qf = self._r(q)
+        qf, kf, vf = self._r(q).clone(), self._r(k).clone(), self._r(v).clone()
+        if part != "all":     # slabs the call may not read: poison them (the HIP kernels never touch them)
+            unread = [0] if part == "bank" else [1, 2]
+            vf.view(3, K, -1)[unread] = float("nan")
+            qk_unread = [1, 2] if (part == "source" or inject) else [0]
+            qf.view(3, Kq, -1)[qk_unread] = float("nan")
+            kf.view(3, K, -1)[qk_unread] = float("nan")
         if Kq != K:      # queries of a frame subset: embed at their global positions, slice the result
             full = torch.zeros(3, K, *q.shape[1:])
             full[:, q_frame0:q_frame0 + Kq] = qf.view(3, Kq, *q.shape[1:])
             qf = full.view(3 * K, *q.shape[1:])
-        o = orc.ext_attn_core(qf, self._r(k), self._r(v), heads, scale, inject)
+        if part == "all":
+            o = orc.ext_attn_core(qf, kf, vf, heads, scale, inject)
+        else:            # run the oracle with the unread slabs replaced by readable zeros, poison its unused outputs
+            qz, kz, vz = (torch.nan_to_num(t, nan=0.0) for t in (qf, kf, vf))
+            for t, z in ((qf, qz), (kf, kz), (vf, vz)):
+                assert torch.isnan(t).view(3, -1).all(1).tolist() == torch.isnan(t).view(3, -1).any(1).tolist()
+            o = orc.ext_attn_core(qz, kz, vz, heads, scale, inject).clone()
+            o.view(3, -1)[[0] if part == "bank" else [1, 2]] = float("nan")
         if Kq != K:
             o = o.view(3, K, *q.shape[1:])[:, q_frame0:q_frame0 + Kq].reshape(3 * Kq, *q.shape[1:])
-        return self._r(o).to(q.dtype)
+        o = self._r(o).to(q.dtype)
+        if out is None:
+            return o
+        computed = {"all": [0, 1, 2], "bank": [1, 2], "source": [0]}[part]
+        out.view(3, -1)[computed] = o.view(3, -1)[computed]
+        return out
 
     def pivot_inv_norm(self, piv):
         return 1.0 / self._r(piv).norm(dim=-1)

@@ -173,7 +173,7 @@ def test_ext_attn_softmax_spike(d):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("d", [40, 80])
 def test_ext_attn_folded_shift_paths(d, dtype, gain):
-    """The folded-softmax kernels (Dh = 40; Dh = 80 always looks) skip the per-tile maximum while |q'| max|k| - shift stays under a
+    """The folded-softmax kernels (Dh = 40; Dh = 80 is the plain online softmax, run for contrast) skip the per-tile maximum while |q'| max|k| - shift stays under a
     threshold (2^60 headroom in bf16, 2^8 in f16).  gain = 3: the bound holds in bf16, the scores climb
     ~25 binades above the first tile's shift without any rescale; gain = 12: the bound fails, so the
     kernel looks at every tile's maximum and moves the shift in late tiles.  Both in both dtypes, on a
@@ -191,7 +191,37 @@ def test_ext_attn_folded_shift_paths(d, dtype, gain):
         refs = attn_ref(q, k, v, h, d ** -0.5, inject)
         out = ops.ext_attn(q.to(dtype).cuda(), k.to(dtype).cuda(), v.to(dtype).cuda(), h, d ** -0.5, inject)
         assert torch.isfinite(out.float()).all()
-        assert_attn_close(out, refs, f"shift paths d={d} {dtype} gain={gain} inject={inject}", dtype=dtype, folded=True)
+        assert_attn_close(out, refs, f"shift paths d={d} {dtype} gain={gain} inject={inject}", dtype=dtype,
+                          folded=d == 40)
+
+
+@pytest.mark.parametrize("K,S,h,d", [(3, 320, 2, 40), (2, 136, 2, 40), (2, 520, 2, 64), (2, 264, 1, 80), (2, 72, 1, 160)])
+@pytest.mark.parametrize("inject", [False, True])
+def test_ext_attn_bank_and_source_parts(K, S, h, d, inject):
+    """TF_ATTN_BANK_ONLY + TF_ATTN_SOURCE_ONLY together reproduce the full call bit for bit, write nothing
+    outside their branches and never read the slabs they do not need (poisoned with NaN here)."""
+    ops = _ops()
+    D = h * d
+    g = torch.Generator(device="cuda").manual_seed(23)
+    q, k, v = (torch.randn(3 * K, S, D, generator=g, device="cuda").bfloat16() for _ in range(3))
+    full = ops.ext_attn(q, k, v, h, d ** -0.5, inject)
+    nan = float("nan")
+
+    def poisoned(t, branches):
+        t = t.clone()
+        t.view(3, -1)[branches] = nan
+        return t
+    qk_unread = [1, 2] if inject else [0]
+    out = torch.full_like(full, 7.0)
+    ops.ext_attn(poisoned(q, qk_unread), poisoned(k, qk_unread), poisoned(v, [0]), h, d ** -0.5, inject, out=out,
+                 part="bank")
+    assert torch.equal(out.view(3, -1)[1:], full.view(3, -1)[1:])
+    assert bool((out.view(3, -1)[0] == 7.0).all())
+    out = torch.full_like(full, 7.0)
+    ops.ext_attn(poisoned(q, [1, 2]), poisoned(k, [1, 2]), poisoned(v, [1, 2]), h, d ** -0.5, inject, out=out,
+                 part="source")
+    assert torch.equal(out.view(3, -1)[0], full.view(3, -1)[0])
+    assert bool((out.view(3, -1)[1:] == 7.0).all())
 
 
 def test_ext_attn_argument_errors():

@@ -30,7 +30,7 @@ def _data(K, n, S, h, d, seed=0):
     return q, k, v, piv, kf_out, tgt, res
 
 
-def _worker(rank, world, port, K, n, S, h, d, inject, ret):
+def _worker(rank, world, port, K, n, S, h, d, inject, mode, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -54,8 +54,12 @@ def _worker(rank, world, port, K, n, S, h, d, inject, ret):
         sh = sharded.FrameShard(K)
         Kl, f0 = sh.Kl, sh.kf0
         loc = lambda t: t.view(3, K, S, D)[:, f0:f0 + Kl].reshape(3 * Kl, S, D)
-        out = sh.pivotal_attention(loc(q), loc(k), loc(v), h, d ** -0.5, inject)
+        fake.calls.clear()
+        out = sh.pivotal_attention(loc(q), loc(k), loc(v), h, d ** -0.5, inject, mode=mode)
         ok = torch.equal(out, loc(full_attn))
+        parts = [c[3] if len(c) > 3 else "all" for c in fake.calls if c[0] == "ext_attn"]
+        want = ["source", "bank"] if (mode or ("heads" if h % world == 0 else "bank")) == "heads" else ["all"]
+        ok = ok and parts == want
         piv_e, inv_e, kfo_e = sh.exchange_halo(piv[f0:f0 + Kl], inv[f0:f0 + Kl], loc(kf_out))
         for j in range(Kl):
             y = sh.propagate(j, tgt[f0 + j], res[f0 + j], piv_e, inv_e, kfo_e, w, n)
@@ -66,12 +70,15 @@ def _worker(rank, world, port, K, n, S, h, d, inject, ret):
 
 
 @pytest.mark.parametrize("inject", [False, True])
-def test_sharded_equals_single_process(inject):
-    world, K, n, S, h, d = 2, 4, 2, 12, 2, 8
+@pytest.mark.parametrize("mode,h", [("heads", 2), ("bank", 2), (None, 4), (None, 3)])
+def test_sharded_equals_single_process(inject, mode, h):
+    """Both exchange patterns of the pivotal pass (head re-sharding, bank all-gather) and the default choice
+    (heads when they divide over the ranks: h = 4 -> heads, h = 3 -> bank)."""
+    world, K, n, S, d = 2, 4, 2, 12, 8
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, K, n, S, h, d, inject, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, K, n, S, h, d, inject, mode, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
 
 

@@ -18,12 +18,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, inject, ret):
+def _worker(rank, world, port, inject, mode, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from tokenflow_amd import ops, sharded
         torch.cuda.set_device(0)
+
         K, n, S, h, d = 4, 2, 320, 2, 40
         D = h * d
         g = torch.Generator().manual_seed(0)
@@ -44,7 +45,7 @@ def _worker(rank, world, port, inject, ret):
         sh = sharded.FrameShard(K)
         Kl, f0 = sh.Kl, sh.kf0
         loc = lambda t: t.view(3, K, S, D)[:, f0:f0 + Kl].reshape(3 * Kl, S, D)
-        out = sh.pivotal_attention(loc(q), loc(k), loc(v), h, d ** -0.5, inject)
+        out = sh.pivotal_attention(loc(q), loc(k), loc(v), h, d ** -0.5, inject, mode=mode)
         ok = torch.equal(out, loc(full))
         pe, ie, ke = sh.exchange_halo(piv[f0:f0 + Kl], inv[f0:f0 + Kl], out)
         for j in range(Kl):
@@ -56,9 +57,10 @@ def _worker(rank, world, port, inject, ret):
 
 
 @pytest.mark.parametrize("inject", [False, True])
-def test_sharded_real_kernels_two_ranks(inject):
+@pytest.mark.parametrize("mode", ["heads", "bank"])
+def test_sharded_real_kernels_two_ranks(inject, mode):
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, inject, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, inject, mode, ret), nprocs=2, join=True)
     assert dict(ret) == {0: True, 1: True}

@@ -65,7 +65,8 @@ struct AttnParams {
     const void* vt;
     const float* knorm2;  // [3][H][K*Spad/64] max |k|^2 per 64-key block, FOLD kernels only (from vt_pack_kernel)
     void* out;
-    int K, Kq, q_frame0, S, H, Spad, nQT, inject, exact_scale;  // K bank frames; queries = frames q_frame0 .. +Kq
+    int K, Kq, q_frame0, S, H, Spad, nQT, inject, exact_scale;
+    int part;  // 0 = all three branches, TF_ATTN_BANK_ONLY, TF_ATTN_SOURCE_ONLY  // K bank frames; queries = frames q_frame0 .. +Kq
     int64_t ld;
     float c;  // scale * log2(e)
 };
@@ -97,22 +98,25 @@ template <typename T>
 __global__ __launch_bounds__(256) void vt_pack_kernel(const typename T::elem* __restrict__ v,
                                                       typename T::elem* __restrict__ vt,
                                                       const typename T::elem* __restrict__ k,
-                                                      float* __restrict__ knorm2, int k_branches, int K, int S,
-                                                      int H, int DH, int Spad, int64_t ld) {
+                                                      float* __restrict__ knorm2, int inject, int bf0, int K,
+                                                      int S, int H, int DH, int Spad, int64_t ld) {
     typedef typename T::elem E;
     typedef typename T::vec8 vec8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     E* tile = reinterpret_cast<E*>(smem);  // [64][DH + 2]
     const int row = DH + 2;
     const int ppr = DH >> 3;               // 16-B pieces per V row
-    const int tt = blockIdx.x, h = blockIdx.y, bf = blockIdx.z;  // bf = b*K + f
+    const int tt = blockIdx.x, h = blockIdx.y, bf = blockIdx.z + bf0;  // bf = b*K + f; bf0 = first (branch, frame)
     const int b = bf / K, f = bf - b * K;
     const E* src = v + ((int64_t)bf * S) * ld + h * DH;
-    if (k != nullptr && b < k_branches && threadIdx.x < 64) {   // wave 0: one key per lane
+    // keys of branch b without injection; with injection every branch reads the SOURCE keys, whose norms the
+    // first packed branch computes
+    if (k != nullptr && (!inject || b == bf0 / K) && threadIdx.x < 64) {   // wave 0: one key per lane
+        const int kb = inject ? 0 : b;
         const int kk = tt * 64 + (int)threadIdx.x;
         float acc = 0.f;
         if (kk < S) {
-            const E* kp = k + ((int64_t)bf * S + kk) * ld + h * DH;
+            const E* kp = k + (((int64_t)kb * K + f) * S + kk) * ld + h * DH;
             for (int c8 = 0; c8 < DH; c8 += 8) {
                 const vec8 x = __builtin_bit_cast(vec8, ld16(kp + c8));
 #pragma unroll
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const typename T::elem* __
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc = fmaxf(acc, __shfl_xor(acc, o));
-        if (threadIdx.x == 0) knorm2[((int64_t)(b * H + h) * K + f) * (Spad / 64) + tt] = acc;
+        if (threadIdx.x == 0) knorm2[((int64_t)(kb * H + h) * K + f) * (Spad / 64) + tt] = acc;
     }
     for (int id = threadIdx.x; id < 64 * ppr; id += 256) {
         const int key = id / ppr, pc = id - key * ppr;
@@ -188,10 +192,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     //   score of any tile can exceed the threshold and the max3 chain + permlane (16 of ~66 VALU per tile)
     //   is skipped; a query whose bound is loose falls back to the per-tile maximum.  exp2 of FOLD_T must
     //   stay far inside the input type's range with room for the row sum: 2^60 for bf16, 2^8 for f16.
-    //   Measured (MI355X, cfg2): -6.5 % on the Dh = 40 kernel; nothing at Dh = 80, whose tile is MFMA-heavier
-    //   (the extra K read of the pre-pass then costs more than it saves), so the bound is used at Dh = 40 only.
+    //   Measured (MI355X, cfg2 level 0): -6.5 % kernel time for +7..15 us in the pre-pass.
     constexpr float FOLD_T = std::is_same<E, _Float16>::value ? 8.0f : 60.0f;
-    constexpr bool BOUND = FOLD && DH == 40;
+    constexpr bool BOUND = FOLD;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     auto sK = [&](int buf) { return reinterpret_cast<E*>(smem) + buf * BUF_ELEMS; };
@@ -928,7 +931,8 @@ int launch_pp(AttnParams p, hipStream_t st) {
                               (int)lds);
     p.nQT = (p.S + 255) / 256;
     const int per_branch = p.Kq * p.nQT * p.H;
-    const unsigned grid = (unsigned)(MODE == MODE_ALL ? 3 * per_branch : per_branch);
+    // bank problems are decoded first: a bank-only launch simply stops before the source problems
+    const unsigned grid = (unsigned)(MODE == MODE_ALL ? (p.part == TF_ATTN_BANK_ONLY ? 2 : 3) * per_branch : per_branch);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p);
     TF_LAUNCH_CHECK("tf_ext_attn_fwd");
     return 0;
@@ -943,7 +947,8 @@ int launch_one(AttnParams p, hipStream_t st) {
                               (int)lds);
     p.nQT = (p.S + 32 * QT * NW - 1) / (32 * QT * NW);
     const int per_branch = p.Kq * p.nQT * p.H;
-    const unsigned grid = (unsigned)(MODE == MODE_ALL ? 3 * per_branch : per_branch);
+    // bank problems are decoded first: a bank-only launch simply stops before the source problems
+    const unsigned grid = (unsigned)(MODE == MODE_ALL ? (p.part == TF_ATTN_BANK_ONLY ? 2 : 3) * per_branch : per_branch);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, p);
     TF_LAUNCH_CHECK("tf_ext_attn_fwd");
     return 0;
@@ -956,56 +961,57 @@ int launch_one(AttnParams p, hipStream_t st) {
 template <typename T, int DH>
 int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
     typedef typename T::elem E;
-    {   // pre-pass: V -> transposed, key-permuted, per-frame padded bank
-        dim3 grid((unsigned)(p.Spad / 64), (unsigned)p.H, (unsigned)(3 * p.K));
+    const bool src_only = p.part == TF_ATTN_SOURCE_ONLY, bank_only = p.part == TF_ATTN_BANK_ONLY;
+    {   // pre-pass: V -> transposed, key-permuted, per-frame padded bank (only the branches this call computes)
+        const int b_lo = bank_only ? 1 : 0, b_hi = src_only ? 1 : 3;
+        dim3 grid((unsigned)(p.Spad / 64), (unsigned)p.H, (unsigned)((b_hi - b_lo) * p.K));
         const size_t lds = (size_t)64 * (DH + 2) * sizeof(E);
-        // the folded-softmax kernels of Dh = 40 also need the key norm bounds (branch 0 only under injection)
+        // the folded-softmax kernels of Dh = 40 also need the key norm bounds
         const bool fold = DH == 40 && !p.exact_scale;
         hipLaunchKernelGGL(vt_pack_kernel<T>, grid, dim3(256), lds, st, reinterpret_cast<const E*>(v),
                            reinterpret_cast<E*>(const_cast<void*>(p.vt)),
                            fold ? reinterpret_cast<const E*>(p.k) : nullptr, const_cast<float*>(p.knorm2),
-                           p.inject ? 1 : 3, p.K, p.S, p.H, DH, p.Spad, p.ld);
+                           p.inject, b_lo * p.K, p.K, p.S, p.H, DH, p.Spad, p.ld);
         TF_LAUNCH_CHECK("tf_ext_attn_fwd(vt_pack)");
     }
+    // Every head dim has three forms: ALL (one launch, bank problems then source problems), DUAL (injection:
+    // uncond + cond share QK^T and the softmax; pays from S = 256 on) and SOURCE (the source branch alone).
+    // A full call is ALL, or DUAL followed by SOURCE; a bank-only call drops the source part, a source-only
+    // call is SOURCE alone.
+    auto compose = [&](auto all, auto dual, auto source) -> int {
+        if (src_only) return source();
+        if (!p.inject || p.S < 256) return all();   // short frames: the ALL form reads the source q, k itself
+        const int rc = dual();
+        return (rc || bank_only) ? rc : source();
+    };
     if constexpr (DH == 40) {
-        if (p.S >= 256) {
-            // 8-wave (256-query) workgroups only while they still give >= 4 workgroups per CU; a frame-sharded
-            // rank with few query frames takes the 4-wave form (twice the workgroups)
-            const bool big = (int64_t)3 * p.Kq * ((p.S + 255) / 256) * p.H >= 1024;
-            if (p.exact_scale) {   // fp32 score scaling (TF_ATTN_EXACT_SCALE)
-                if (p.inject) {
-                    const int rc = launch_one<T, DH, 1, 4, MODE_DUAL, 3, false>(p, st);
-                    if (rc) return rc;
-                    return big ? launch_one<T, DH, 1, 8, MODE_SOURCE, 2, false>(p, st)
-                               : launch_one<T, DH, 1, 4, MODE_SOURCE, 2, false>(p, st);
-                }
-                return big ? launch_one<T, DH, 1, 8, MODE_ALL, 2, false>(p, st)
-                           : launch_one<T, DH, 1, 4, MODE_ALL, 2, false>(p, st);
-            }
-            if (p.inject) {   // 151 VGPRs: 4-wave workgroups, 3 per CU
-                const int rc = launch_one<T, DH, 1, 4, MODE_DUAL, 3>(p, st);
-                if (rc) return rc;
-                return big ? launch_one<T, DH, 1, 8, MODE_SOURCE, 2>(p, st) : launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st);
-            }
-            return big ? launch_one<T, DH, 1, 8, MODE_ALL, 2>(p, st) : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st);
-        }
-        if (p.exact_scale) return launch_one<T, DH, 1, 4, MODE_ALL, 2, false>(p, st);
-        return launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st);
+        // 8-wave (256-query) workgroups only while they still give >= 4 workgroups per CU; a sharded rank with
+        // few query frames or heads takes the 4-wave form (twice the workgroups).  S < 256: always 4 waves.
+        const bool big = p.S >= 256 && (int64_t)3 * p.Kq * ((p.S + 255) / 256) * p.H >= 1024;
+        if (p.exact_scale)   // fp32 score scaling (TF_ATTN_EXACT_SCALE)
+            return compose([&] { return big ? launch_one<T, DH, 1, 8, MODE_ALL, 2, false>(p, st)
+                                            : launch_one<T, DH, 1, 4, MODE_ALL, 2, false>(p, st); },
+                           [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 3, false>(p, st); },
+                           [&] { return big ? launch_one<T, DH, 1, 8, MODE_SOURCE, 2, false>(p, st)
+                                            : launch_one<T, DH, 1, 4, MODE_SOURCE, 2, false>(p, st); });
+        return compose([&] { return big ? launch_one<T, DH, 1, 8, MODE_ALL, 2>(p, st)
+                                        : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st); },
+                       [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 3>(p, st); },   // 151 VGPRs: 3 workgroups per CU
+                       [&] { return big ? launch_one<T, DH, 1, 8, MODE_SOURCE, 2>(p, st)
+                                        : launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st); });
     } else if constexpr (DH == 64) {
-        if (p.inject && p.S >= 256) {
-            const int rc = launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st);
-            return rc ? rc : launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st);
-        }
-        if (p.S >= 512) return launch_pp<T, DH, MODE_ALL, 2>(p, st);   // ping-pong: +8..11 % over the plain 2-tile form
-        return launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st);
+        return compose([&] { return p.S >= 512 ? launch_pp<T, DH, MODE_ALL, 2>(p, st)   // ping-pong: +8..11 %
+                                               : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st); },
+                       [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st); },
+                       [&] { return launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st); });
     } else if constexpr (DH == 80) {
-        if (p.inject && p.S >= 256) {
-            const int rc = launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st);
-            return rc ? rc : launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st);
-        }
-        return launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st);
+        return compose([&] { return launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st); },
+                       [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st); },
+                       [&] { return launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st); });
     } else {
-        // Dh=160: the dual (shared-softmax) form needs 160 more accumulator registers and measured slower
+        // Dh=160: the dual (shared-softmax) form needs 160 more accumulator registers and measured slower;
+        // under injection the ALL form reads the source q and k for every branch instead
+        if (src_only) return launch_one<T, DH, 1, 4, MODE_SOURCE, 1>(p, st);
         return launch_one<T, DH, 1, 4, MODE_ALL, 1>(p, st);
     }
 }
@@ -1059,6 +1065,9 @@ extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void
     p.Spad = ((S + 127) / 128) * 128;
     p.nQT = (S + 127) / 128;
     p.inject = (inject & TF_ATTN_INJECT) ? 1 : 0;
+    p.part = inject & (TF_ATTN_BANK_ONLY | TF_ATTN_SOURCE_ONLY);
+    TF_ARG(p.part != (TF_ATTN_BANK_ONLY | TF_ATTN_SOURCE_ONLY), TF_ERR_SHAPE,
+           "tf_ext_attn_fwd: TF_ATTN_BANK_ONLY and TF_ATTN_SOURCE_ONLY exclude each other");
     p.exact_scale = (inject & TF_ATTN_EXACT_SCALE) ? 1 : 0;
     p.ld = ld;
     p.c = (float)((double)scale * 1.4426950408889634);

@@ -44,10 +44,12 @@ EXACT_SCALE = os.environ.get("TOKENFLOW_EXACT_SCALE", "0") not in ("", "0")
 
 def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float,
              inject: bool, out: Optional[torch.Tensor] = None, q_frame0: int = 0,
-             exact_scale: Optional[bool] = None) -> torch.Tensor:
+             exact_scale: Optional[bool] = None, part: str = "all") -> torch.Tensor:
     """Extended attention core (tokenflow_utils.py:124-197).  k,v: [3K,S,D] bf16/f16 (the bank),
     q: [3Kq,S,D] = the queries of keyframes q_frame0..q_frame0+Kq-1 (Kq = K on one GPU); last dim
-    contiguous, equal token stride.  Returns [3Kq,S,D] in the same dtype."""
+    contiguous, equal token stride.  Returns [3Kq,S,D] in the same dtype.
+    part = "bank": only the uncond/cond branches are computed (the source slabs of v and out, and those
+    of q, k that the call does not read, are never touched); part = "source": only the source branch."""
     _need_gpu(q, k, v)
     lib = _lib.load()
     B, S, D = k.shape
@@ -71,6 +73,7 @@ def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scal
     if out is None:
         out = torch.empty(Bq, S, D, dtype=q.dtype, device=q.device)
     flags = (1 if inject else 0) | (2 if (EXACT_SCALE if exact_scale is None else exact_scale) else 0)
+    flags |= {"all": 0, "bank": _lib.TF_ATTN_BANK_ONLY, "source": _lib.TF_ATTN_SOURCE_ONLY}[part]
     nbytes = lib.tf_ext_attn_workspace_bytes(K, S, heads, dh, dt)
     ws = _workspace(nbytes, q.device)
     _lib.check(lib.tf_ext_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), K, Kq, int(q_frame0),

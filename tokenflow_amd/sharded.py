@@ -3,23 +3,36 @@
 The reference is single-process (no parallelism of any kind); this is new.
 Rank r of W owns the contiguous chunks [r*C/W, (r+1)*C/W) of the video and the keyframes
 drawn from them (K = C keyframes, one per chunk, run_tokenflow_pnp.py:224).  Per block there
-are exactly two exchange steps, both through torch.distributed (backend "nccl" = RCCL over
-xGMI on MI355X; "gloo" in the CPU tests):
+are two exchange steps, both through torch.distributed (backend "nccl" = RCCL over xGMI on
+MI355X; "gloo" in the CPU tests):
 
- 1. pivotal pass -- all-gather of the key/value bank: every query of a local keyframe
-    attends to the keys/values of ALL K keyframes of its branch (tokenflow_utils.py:133-138).
-    Only what is read remotely travels: without injection K and V of uncond and cond
-    (4 slabs of [K/W,S,D]); with q/k injection (124-130) the key bank is the SOURCE branch's
-    for both, so 3 slabs.  Each slab is gathered straight into its place in the
-    [3,K,S,D] bank the kernel reads (no re-layout copy); the source branch's own frames are
-    copied locally.  `ops.ext_attn(q_local, k_bank, v_bank, q_frame0=...)` then computes only
-    the local keyframes' queries.
+ 1. pivotal pass -- every query of a keyframe attends to the keys/values of ALL K keyframes
+    of its branch (tokenflow_utils.py:133-138).  Two exchange patterns, same results:
+
+    "heads" (default when heads % W == 0): the bank branches are re-sharded from frames to
+        heads for the attention and back.  Rank r sends, to every rank w, head group w of its
+        keyframes' q, k, v (uncond + cond; with q/k injection, 124-130, the source q, k and
+        the uncond/cond v), receives head group r of everybody's keyframes, runs
+        `ops.ext_attn(part="bank")` on [3,K,S,D/W], and returns the outputs the same way.
+        Two all-to-alls per block; a rank moves (6+2)*(W-1)/W (injection: (4+2)*(W-1)/W)
+        slabs of [K/W,S,D/W]... i.e. ~8 local slabs in total, independent of W, and on a
+        fully connected xGMI mesh every pair uses its own link.  The source branch (own-frame
+        keys only, 173/177) never leaves the rank: `ops.ext_attn(part="source")` runs on the
+        local frames while the first exchange is in flight.
+    "bank": all-gather of the key/value bank.  Only what is read remotely travels: without
+        injection K and V of uncond and cond (4 slabs of [K/W,S,D] per rank, gathered to
+        [K,S,D]); with injection 3 slabs.  Each slab is gathered straight into its place in
+        the [3,K,S,D] bank the kernel reads; `ops.ext_attn(q_local, k_bank, v_bank,
+        q_frame0=...)` then computes only the local keyframes' queries.  A rank receives
+        4*(W-1) local slabs: 4x the "heads" volume at W = 8, and ring-bound.
+
  2. propagation passes -- chunk c needs keyframes c and c-1 (331-333): the first local chunk's
     left neighbour lives on rank r-1, so each rank sends its LAST keyframe's pivot features,
     inverse norms and attention output to rank r+1 (one point-to-point message per block).
 
 Work is partitioned, not re-associated: every output element is produced by exactly the same
-kernel arithmetic as on one GPU, so sharded results equal single-process results bit for bit.
+kernel arithmetic as on one GPU (the attention of one (query, head) visits the K frames in the
+same order, whoever computes it), so sharded results equal single-process results bit for bit.
 """
 from typing import Optional, Tuple
 
@@ -27,6 +40,22 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def _all_to_all(recv: torch.Tensor, send: torch.Tensor, group, async_op: bool = False):
+    """dist.all_to_all_single; gloo (development boxes, the single-GPU tests) moves host memory only, so
+    device tensors are staged through the host there.  RCCL takes the device buffers directly."""
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(send.shape, dtype=send.dtype)
+        dist.all_to_all_single(host, send.cpu(), group=group)
+        recv.copy_(host)
+        return _Done() if async_op else None
+    return dist.all_to_all_single(recv, send, group=group, async_op=async_op)
 
 
 class FrameShard:
@@ -66,10 +95,59 @@ class FrameShard:
             w.wait()
         return kb.view(3 * K, S, D), vb.view(3 * K, S, D)
 
-    def pivotal_attention(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool):
-        """Extended attention for the local keyframes against the all-gathered bank -> [3*Kl,S,D]."""
+    def pivotal_attention(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool,
+                          mode: Optional[str] = None):
+        """Extended attention for the local keyframes against all K keyframes -> [3*Kl,S,D].
+        mode: "heads" | "bank" | None (= "heads" when the heads divide over the ranks)."""
+        if self.world == 1:
+            return ops.ext_attn(q_local, k_local, v_local, heads, scale, inject)
+        if mode is None:
+            mode = "heads" if heads % self.world == 0 else "bank"
+        if mode == "heads":
+            return self._pivotal_heads(q_local, k_local, v_local, heads, scale, inject)
         kb, vb = self.gather_bank(k_local, v_local, inject)
         return ops.ext_attn(q_local, kb, vb, heads, scale, inject, q_frame0=self.kf0)
+
+    def _pivotal_heads(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool):
+        W, Kl, K = self.world, self.Kl, self.K
+        B, S, D = q_local.shape
+        if heads % W:
+            raise ValueError(f"{heads} heads do not divide over {W} ranks")
+        hd, dev, dt = D // W, q_local.device, q_local.dtype
+        q3, k3, v3 = (t.contiguous().view(3, Kl, S, W, hd) for t in (q_local, k_local, v_local))
+        # ---- pack: send[w] = head group w of every slab the bank branches read   [W, ns, Kl, S, hd]
+        ns = 4 if inject else 6
+        send = torch.empty(W, ns, Kl, S, hd, dtype=dt, device=dev)
+        if inject:       # source q, k (what uncond and cond use, 124-130) and the two value banks
+            send[:, 0].copy_(q3[0].permute(2, 0, 1, 3))
+            send[:, 1].copy_(k3[0].permute(2, 0, 1, 3))
+            send[:, 2:4].copy_(v3[1:3].permute(3, 0, 1, 2, 4))
+        else:
+            sv = send.view(W, 3, 2, Kl, S, hd)
+            for t, x in enumerate((q3, k3, v3)):
+                sv[:, t].copy_(x[1:3].permute(3, 0, 1, 2, 4))
+        recv = torch.empty_like(send)
+        work = _all_to_all(recv, send, self.group, async_op=True)
+        # ---- source branch: own-frame keys, all heads, stays local (overlaps the exchange)
+        out = torch.empty(3, Kl, S, D, dtype=dt, device=dev)
+        ops.ext_attn(q_local, k_local, v_local, heads, scale, inject, out=out.view(3 * Kl, S, D), part="source")
+        work.wait()
+        # ---- unpack: recv[w] holds rank w's keyframes (global frames w*Kl ..) for MY head group
+        bank = torch.empty(3, 3, K, S, hd, dtype=dt, device=dev)     # [q|k|v][branch][frame]; unread slabs stay unset
+        if inject:
+            bank[0, 0].view(W, Kl, S, hd).copy_(recv[:, 0])
+            bank[1, 0].view(W, Kl, S, hd).copy_(recv[:, 1])
+            bank[2, 1:3].view(2, W, Kl, S, hd).copy_(recv[:, 2:4].permute(1, 0, 2, 3, 4))
+        else:
+            bank[:, 1:3].view(3, 2, W, Kl, S, hd).copy_(recv.view(W, 3, 2, Kl, S, hd).permute(1, 2, 0, 3, 4, 5))
+        oh = ops.ext_attn(bank[0].view(3 * K, S, hd), bank[1].view(3 * K, S, hd), bank[2].view(3 * K, S, hd),
+                          heads // W, scale, inject, part="bank")
+        # ---- outputs back to the frame owners: [W(dest), 2, Kl, S, hd] -> head group w of my frames
+        send2 = oh.view(3, W, Kl, S, hd)[1:3].permute(1, 0, 2, 3, 4).contiguous()
+        recv2 = torch.empty_like(send2)
+        _all_to_all(recv2, send2, self.group)
+        out.view(3, Kl, S, W, hd)[1:3].copy_(recv2.permute(1, 2, 3, 0, 4))
+        return out.view(3 * Kl, S, D)
 
     # ------------------------------------------------------------------ halo for propagation
     def exchange_halo(self, pivots_local: torch.Tensor, inv_local: torch.Tensor, kf_out_local: torch.Tensor):
