@@ -82,7 +82,21 @@ def test_sharded_equals_single_process(inject, mode, h):
     assert dict(ret) == {0: True, 1: True}
 
 
-def test_uneven_shards_rejected():
+@pytest.mark.parametrize("inject", [False, True])
+@pytest.mark.parametrize("mode", ["heads", "bank"])
+def test_uneven_shards(inject, mode):
+    """K = 5 keyframes over 2 ranks -> runs of 3 and 2 (cfg5 is 4,3,3,3,3,3,3,3)."""
+    world, K, n, S, h, d = 2, 5, 2, 12, 2, 8
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, K, n, S, h, d, inject, mode, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_shard_runs():
     from tokenflow_amd import sharded
-    sh = sharded.FrameShard(5)          # world 1: fine
-    assert sh.Kl == 5 and sh.kf0 == 0
+    sh = sharded.FrameShard(5)          # world 1
+    assert (sh.Kl, sh.kf0, sh.counts, sh.even) == (5, 0, [5], True)
+    one = sharded.FrameShard.__new__(sharded.FrameShard)
+    assert [K // 8 + (1 if r < K % 8 else 0) for K in (25,) for r in range(8)] == [4, 3, 3, 3, 3, 3, 3, 3]

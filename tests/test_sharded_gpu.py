@@ -18,14 +18,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, inject, mode, ret):
+def _worker(rank, world, port, K, inject, mode, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from tokenflow_amd import ops, sharded
         torch.cuda.set_device(0)
 
-        K, n, S, h, d = 4, 2, 320, 2, 40
+        n, S, h, d = 2, 320, 2, 40
         D = h * d
         g = torch.Generator().manual_seed(0)
         q, k, v = (torch.randn(3 * K, S, D, generator=g).bfloat16().cuda() for _ in range(3))
@@ -56,11 +56,13 @@ def _worker(rank, world, port, inject, mode, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("inject", [False, True])
-@pytest.mark.parametrize("mode", ["heads", "bank"])
-def test_sharded_real_kernels_two_ranks(inject, mode):
+@pytest.mark.parametrize("K,mode,inject", [(4, "heads", False), (4, "heads", True), (4, "bank", False),
+                                           (4, "bank", True), (5, "heads", True), (5, "heads", False),
+                                           (5, "bank", False)])
+def test_sharded_real_kernels_two_ranks(K, mode, inject):
+    """K = 5: uneven runs (3 + 2 keyframes)."""
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, inject, mode, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, K, inject, mode, ret), nprocs=2, join=True)
     assert dict(ret) == {0: True, 1: True}

@@ -14,9 +14,9 @@ MI355X; "gloo" in the CPU tests):
         keyframes' q, k, v (uncond + cond; with q/k injection, 124-130, the source q, k and
         the uncond/cond v), receives head group r of everybody's keyframes, runs
         `ops.ext_attn(part="bank")` on [3,K,S,D/W], and returns the outputs the same way.
-        Two all-to-alls per block; a rank moves (6+2)*(W-1)/W (injection: (4+2)*(W-1)/W)
-        slabs of [K/W,S,D/W]... i.e. ~8 local slabs in total, independent of W, and on a
-        fully connected xGMI mesh every pair uses its own link.  The source branch (own-frame
+        Two all-to-alls per block; a rank sends (6+2)*(W-1)/W (injection: (4+2)*(W-1)/W) of
+        its local [K/W,S,D] slabs -- under 8 local slabs whatever W -- and on a fully
+        connected xGMI mesh every pair uses its own link.  The source branch (own-frame
         keys only, 173/177) never leaves the rank: `ops.ext_attn(part="source")` runs on the
         local frames while the first exchange is in flight.
     "bank": all-gather of the key/value bank.  Only what is read remotely travels: without
@@ -47,28 +47,34 @@ class _Done:
         return True
 
 
-def _all_to_all(recv: torch.Tensor, send: torch.Tensor, group, async_op: bool = False):
-    """dist.all_to_all_single; gloo (development boxes, the single-GPU tests) moves host memory only, so
-    device tensors are staged through the host there.  RCCL takes the device buffers directly."""
+def _all_to_all(recv: torch.Tensor, send: torch.Tensor, group, out_rows=None, in_rows=None, async_op: bool = False):
+    """dist.all_to_all_single over dim 0 (row counts per peer; None = equal).  gloo (development boxes, the
+    single-GPU tests) moves host memory only, so device tensors are staged through the host there.  RCCL
+    takes the device buffers directly."""
     if send.is_cuda and dist.get_backend(group) == "gloo":
-        host = torch.empty(send.shape, dtype=send.dtype)
-        dist.all_to_all_single(host, send.cpu(), group=group)
+        host = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(host, send.cpu(), out_rows, in_rows, group=group)
         recv.copy_(host)
         return _Done() if async_op else None
-    return dist.all_to_all_single(recv, send, group=group, async_op=async_op)
+    return dist.all_to_all_single(recv, send, out_rows, in_rows, group=group, async_op=async_op)
 
 
 class FrameShard:
+    """K keyframes (= chunks) over the ranks of `group` in contiguous runs; the first K % W ranks hold one more
+    (cfg5's 25 chunks over 8 ranks -> 4,3,3,3,3,3,3,3)."""
+
     def __init__(self, K: int, group: Optional[dist.ProcessGroup] = None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        if K % self.world:
-            raise ValueError(f"{K} keyframes do not divide over {self.world} ranks "
-                             "(uneven frame shards are not supported yet)")
+        if K < self.world:
+            raise ValueError(f"{K} keyframes cannot be sharded over {self.world} ranks (a rank would own none)")
         self.K = K
-        self.Kl = K // self.world            # local keyframes == local chunks
-        self.kf0 = self.rank * self.Kl       # first global keyframe / chunk of this rank
+        self.counts = [K // self.world + (1 if r < K % self.world else 0) for r in range(self.world)]
+        self.offsets = [sum(self.counts[:r]) for r in range(self.world)]
+        self.even = K % self.world == 0
+        self.Kl = self.counts[self.rank]       # local keyframes == local chunks
+        self.kf0 = self.offsets[self.rank]     # first global keyframe / chunk of this rank
 
     # ------------------------------------------------------------------ pivotal pass
     def gather_bank(self, k_local: torch.Tensor, v_local: torch.Tensor, inject: bool
@@ -77,22 +83,32 @@ class FrameShard:
         if self.world == 1:
             return k_local, v_local
         B, S, D = k_local.shape
-        Kl, K = self.Kl, self.K
+        Kl, K, W = self.Kl, self.K, self.world
         kl, vl = k_local.contiguous().view(3, Kl, S, D), v_local.contiguous().view(3, Kl, S, D)
         kb = torch.empty(3, K, S, D, dtype=k_local.dtype, device=k_local.device)
         vb = torch.empty(3, K, S, D, dtype=v_local.dtype, device=v_local.device)
         sl = slice(self.kf0, self.kf0 + Kl)
-        works = []
+        works, pads = [], []
         for b in range(3):
             k_remote = (b == 0) if inject else (b > 0)     # key bank read across frames?
             v_remote = b > 0
             for need, bank, loc in ((k_remote, kb, kl), (v_remote, vb, vl)):
-                if need:
-                    works.append(dist.all_gather_into_tensor(bank[b], loc[b], group=self.group, async_op=True))
-                else:
+                if not need:
                     bank[b, sl].copy_(loc[b])               # only this rank's own frames are read
+                elif self.even:                             # straight into place, no re-layout
+                    works.append(dist.all_gather_into_tensor(bank[b], loc[b], group=self.group, async_op=True))
+                else:                                       # uneven runs: equal-size padded contributions
+                    Km = self.counts[0]
+                    mine = torch.zeros(Km, S, D, dtype=loc.dtype, device=loc.device)
+                    mine[:Kl].copy_(loc[b])
+                    allp = torch.empty(W * Km, S, D, dtype=loc.dtype, device=loc.device)
+                    works.append(dist.all_gather_into_tensor(allp, mine, group=self.group, async_op=True))
+                    pads.append((bank[b], allp.view(W, Km, S, D)))
         for w in works:
             w.wait()
+        for dst, allp in pads:
+            for r in range(W):
+                dst[self.offsets[r]:self.offsets[r] + self.counts[r]].copy_(allp[r, :self.counts[r]])
         return kb.view(3 * K, S, D), vb.view(3 * K, S, D)
 
     def pivotal_attention(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool,
@@ -115,38 +131,43 @@ class FrameShard:
             raise ValueError(f"{heads} heads do not divide over {W} ranks")
         hd, dev, dt = D // W, q_local.device, q_local.dtype
         q3, k3, v3 = (t.contiguous().view(3, Kl, S, W, hd) for t in (q_local, k_local, v_local))
-        # ---- pack: send[w] = head group w of every slab the bank branches read   [W, ns, Kl, S, hd]
+        even = self.even
+        # ---- pack, frame-major: send[w, f] = head group w of every slab of local keyframe f that the bank
+        #      branches read.  The ranks' runs are contiguous and in rank order, so what arrives is already
+        #      [K (global frame), ns, S, hd] whatever the run lengths.
         ns = 4 if inject else 6
-        send = torch.empty(W, ns, Kl, S, hd, dtype=dt, device=dev)
+        send = torch.empty(W, Kl, ns, S, hd, dtype=dt, device=dev)
         if inject:       # source q, k (what uncond and cond use, 124-130) and the two value banks
-            send[:, 0].copy_(q3[0].permute(2, 0, 1, 3))
-            send[:, 1].copy_(k3[0].permute(2, 0, 1, 3))
-            send[:, 2:4].copy_(v3[1:3].permute(3, 0, 1, 2, 4))
+            send[:, :, 0].copy_(q3[0].permute(2, 0, 1, 3))
+            send[:, :, 1].copy_(k3[0].permute(2, 0, 1, 3))
+            send[:, :, 2:4].copy_(v3[1:3].permute(3, 1, 0, 2, 4))
         else:
-            sv = send.view(W, 3, 2, Kl, S, hd)
+            sv = send.view(W, Kl, 3, 2, S, hd)
             for t, x in enumerate((q3, k3, v3)):
-                sv[:, t].copy_(x[1:3].permute(3, 0, 1, 2, 4))
-        recv = torch.empty_like(send)
-        work = _all_to_all(recv, send, self.group, async_op=True)
+                sv[:, :, t].copy_(x[1:3].permute(3, 1, 0, 2, 4))
+        recv = torch.empty(K, ns, S, hd, dtype=dt, device=dev)
+        work = _all_to_all(recv.view(K, -1), send.view(W * Kl, -1), self.group,
+                           None if even else self.counts, None if even else [Kl] * W, async_op=True)
         # ---- source branch: own-frame keys, all heads, stays local (overlaps the exchange)
         out = torch.empty(3, Kl, S, D, dtype=dt, device=dev)
         ops.ext_attn(q_local, k_local, v_local, heads, scale, inject, out=out.view(3 * Kl, S, D), part="source")
         work.wait()
-        # ---- unpack: recv[w] holds rank w's keyframes (global frames w*Kl ..) for MY head group
-        bank = torch.empty(3, 3, K, S, hd, dtype=dt, device=dev)     # [q|k|v][branch][frame]; unread slabs stay unset
+        # ---- unpack into the [3,K,S,hd] q / k / v the kernel reads; slabs it does not read stay unset
+        bank = torch.empty(3, 3, K, S, hd, dtype=dt, device=dev)     # [q|k|v][branch][frame]
         if inject:
-            bank[0, 0].view(W, Kl, S, hd).copy_(recv[:, 0])
-            bank[1, 0].view(W, Kl, S, hd).copy_(recv[:, 1])
-            bank[2, 1:3].view(2, W, Kl, S, hd).copy_(recv[:, 2:4].permute(1, 0, 2, 3, 4))
+            bank[0, 0].copy_(recv[:, 0])
+            bank[1, 0].copy_(recv[:, 1])
+            bank[2, 1:3].copy_(recv[:, 2:4].permute(1, 0, 2, 3))
         else:
-            bank[:, 1:3].view(3, 2, W, Kl, S, hd).copy_(recv.view(W, 3, 2, Kl, S, hd).permute(1, 2, 0, 3, 4, 5))
+            bank[:, 1:3].copy_(recv.view(K, 3, 2, S, hd).permute(1, 2, 0, 3, 4))
         oh = ops.ext_attn(bank[0].view(3 * K, S, hd), bank[1].view(3 * K, S, hd), bank[2].view(3 * K, S, hd),
                           heads // W, scale, inject, part="bank")
-        # ---- outputs back to the frame owners: [W(dest), 2, Kl, S, hd] -> head group w of my frames
-        send2 = oh.view(3, W, Kl, S, hd)[1:3].permute(1, 0, 2, 3, 4).contiguous()
-        recv2 = torch.empty_like(send2)
-        _all_to_all(recv2, send2, self.group)
-        out.view(3, Kl, S, W, hd)[1:3].copy_(recv2.permute(1, 2, 3, 0, 4))
+        # ---- outputs back to the frame owners, frame-major again: rows of rank w's run go to rank w
+        send2 = oh.view(3, K, S, hd)[1:3].permute(1, 0, 2, 3).contiguous()          # [K, 2, S, hd]
+        recv2 = torch.empty(W, Kl, 2, S, hd, dtype=dt, device=dev)                   # [head group, my frames]
+        _all_to_all(recv2.view(W * Kl, -1), send2.view(K, -1), self.group,
+                    None if even else [Kl] * W, None if even else self.counts)
+        out.view(3, Kl, S, W, hd)[1:3].copy_(recv2.permute(2, 1, 3, 0, 4))
         return out.view(3 * Kl, S, D)
 
     # ------------------------------------------------------------------ halo for propagation
