@@ -403,7 +403,9 @@ struct NnPlan {
 static NnPlan nn_plan(int64_t n_tgt, int S, int D, int P) {
     NnPlan pl;
     pl.rb = D == 320;
-    pl.wide = !pl.rb && ((n_tgt + 127) / 128) * P >= 512;
+    // 128-target panels halve the pivot re-reads; they pay as soon as the grid still fills the GPU after
+    // splitting the pivot range (measured at cfg2 level 1, 5120 targets x 2 keyframes: 34.6 vs 39.8 us)
+    pl.wide = !pl.rb && ((n_tgt + 127) / 128) * P >= 64;
     const int tn = pl.rb ? 128 : (pl.wide ? 128 : 64);
     const int tm = pl.rb ? 32 : TM;
     pl.panels = (n_tgt + tn - 1) / tn;
@@ -459,7 +461,7 @@ int dispatch_nn(const void* tgt, const void* piv, const float* inv_norm, int32_t
                 int S, int D, int P, int kf0, int kf1, hipStream_t st) {
     const NnPlan pl = nn_plan(n_tgt, S, D, P);
     if (pl.rb) return launch_nn_rb<T, 20>(tgt, piv, inv_norm, idx, ws, n_tgt, S, P, kf0, kf1, st);
-    // 128-target panels when they still give >= 2 workgroups per CU, else 64-target panels
+    // 128-target panels for all but the small target sets (nn_plan), else 64-target panels
     if (pl.wide) return launch_nn<T, 2, 64>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st);
     // few workgroups and a long contraction: latency-bound per iteration -> 128-wide D chunks
     if (pl.panels * P * pl.splits <= 512 && D >= 512)
