@@ -23,6 +23,8 @@
 // Parallelism: grid = (target panels, P keyframes, SPLITS of the pivot range).  With SPLITS > 1
 // every workgroup writes its (best score, index) per target to scratch and nn_finalize_kernel
 // merges them in ascending split order (strict '>', so the first index still wins on ties).
+#include <type_traits>
+
 #include "tf_common.h"
 
 namespace {
@@ -114,49 +116,60 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
     const int n_kc = (D + BK - 1) / BK;
     const int total = n_mt * n_kc;
 
-    // per-thread staging pieces: piece id = tid + 256*i -> row = id / PPR, col piece = id % PPR
-    u32x4 ra[NPA], rb[NPB];
-    float rinv = 0.f;
+    // per-thread staging pieces: piece id = tid + 256*i -> row = id / PPR, col piece = id % PPR.
+    // TWO register sets: the loads of chunk it+2 are issued during chunk it and written to LDS at the end of
+    // chunk it+1, so a global-load latency is spread over two iterations (the loop is a serial chain of
+    // load -> LDS -> barrier -> MFMA steps; with one set every step paid the full latency, ~1.7 us, which
+    // is all the time there is at the small levels).
+    u32x4 ra2[2][NPA], rb2[2][NPB];
+    float rinv2[2] = {0.f, 0.f};
 
-    auto stage_load = [&](int it) {
+    auto stage_load = [&](int it, auto SET) {
+        constexpr int set = decltype(SET)::value;
+        u32x4(&ra)[NPA] = ra2[set];
+        u32x4(&rb)[NPB] = rb2[set];
+        float& rinv = rinv2[set];
         const int mt = it / n_kc, kc = it - mt * n_kc;
         const int col0 = kc * BK;
+        // Branch-free: every lane loads from a valid (clamped) address; columns past D are zeroed when the
+        // piece is written to LDS.  A predicated load (col < D ? load : 0) becomes an exec-masked branch per
+        // load and makes the compiler drain vmcnt(0) before the next batch -- no load ever overlapped a MFMA.
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
             const int id = tid + 256 * i;
             const int r = id / PPR, pc = id % PPR;
-            int row = (mt0 + mt) * TM + r;
-            row = row < S ? row : S - 1;  // clamped duplicates can never win (see epilogue)
-            const int col = col0 + pc * 8;
-            ra[i] = col < D ? ld16(pv + (int64_t)row * D + col) : u32x4{0, 0, 0, 0};
+            const int row = min((mt0 + mt) * TM + r, S - 1);   // clamped duplicates can never win (see epilogue)
+            const int col = min(col0 + pc * 8, D - 8);
+            ra[i] = ld16(pv + (int64_t)row * D + col);
         }
 #pragma unroll
         for (int i = 0; i < NPB; ++i) {
             const int id = tid + 256 * i;
             const int r = id / PPR, pc = id % PPR;
-            int64_t row = t0 + r;
-            row = row < n_tgt ? row : n_tgt - 1;
-            const int col = col0 + pc * 8;
-            rb[i] = col < D ? ld16(tgt + row * D + col) : u32x4{0, 0, 0, 0};
+            const int64_t row = min(t0 + r, n_tgt - 1);
+            const int col = min(col0 + pc * 8, D - 8);
+            rb[i] = ld16(tgt + row * D + col);
         }
-        if (kc == 0 && tid < TM) {
-            int row = (mt0 + mt) * TM + tid;
-            row = row < S ? row : S - 1;
-            rinv = inv[row];
-        }
+        rinv = inv[min((mt0 + mt) * TM + min(tid, TM - 1), S - 1)];
     };
-    auto stage_write = [&](int it) {
+    auto stage_write = [&](int it, auto SET) {
+        constexpr int set = decltype(SET)::value;
+        u32x4(&ra)[NPA] = ra2[set];
+        u32x4(&rb)[NPB] = rb2[set];
+        const float rinv = rinv2[set];
         const int mt = it / n_kc, kc = it - mt * n_kc;
         const int b = it & 1;
+        const int col0 = kc * BK;
+        const u32x4 zero = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
             const int id = tid + 256 * i;
-            st16(sA(b) + swz_off<BK>(id / PPR, id % PPR), ra[i]);
+            st16(sA(b) + swz_off<BK>(id / PPR, id % PPR), col0 + (id % PPR) * 8 < D ? ra[i] : zero);
         }
 #pragma unroll
         for (int i = 0; i < NPB; ++i) {
             const int id = tid + 256 * i;
-            st16(sB(b) + swz_off<BK>(id / PPR, id % PPR), rb[i]);
+            st16(sB(b) + swz_off<BK>(id / PPR, id % PPR), col0 + (id % PPR) * 8 < D ? rb[i] : zero);
         }
         if (kc == 0 && tid < TM) sInv[(mt & 1) * TM + tid] = rinv;
     };
@@ -170,14 +183,17 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
         best_i[j] = 0;
     }
 
-    stage_load(0);
-    stage_write(0);
+    typedef std::integral_constant<int, 0> Set0;
+    typedef std::integral_constant<int, 1> Set1;
+    stage_load(0, Set0{});
+    stage_write(0, Set0{});
+    if (total > 1) stage_load(1, Set1{});
     __syncthreads();
 
-    for (int it = 0; it < total; ++it) {
+    // chunk `it` sits in LDS buffer it & 1; register set (it + 1) & 1 holds chunk it + 1, set it & 1 is free
+    auto step = [&](int it, auto CUR, auto NXT) {
         const int mt = it / n_kc, kc = it - mt * n_kc;
-        const bool has_next = it + 1 < total;
-        if (has_next) stage_load(it + 1);
+        if (it + 2 < total) stage_load(it + 2, CUR);
         if (kc == 0) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -223,8 +239,12 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
                 }
             }
         }
-        if (has_next) stage_write(it + 1);
+        if (it + 1 < total) stage_write(it + 1, NXT);
         __syncthreads();
+    };
+    for (int it = 0; it < total; it += 2) {   // unrolled by two so the register sets are compile-time names
+        step(it, Set0{}, Set1{});
+        if (it + 1 < total) step(it + 1, Set1{}, Set0{});
     }
 
     // merge lane l with lane l+32 (interleaved row sets): tie -> smaller index
