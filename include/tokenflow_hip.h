@@ -136,6 +136,23 @@ int tf_gather_blend(const void* kf_out, const int32_t* idx, const float* w, cons
                     int in_dtype, int res_dtype, int out_dtype, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Propagation branch in one call  --  tokenflow_utils.py:329-397 for one chunk:
+ * tf_nn_search followed by tf_gather_blend, without the index tensor in between.
+ * The search leaves its per-split candidates in `ws` and the gather merges them
+ * itself (same order, same tie rule), which saves the finalize launch -- about
+ * 4 us per call, i.e. what a launch costs on this GPU even when it does nothing.
+ * Results are bit-identical to the two separate calls.  n_tgt = n*S; arguments as
+ * in the two functions above; `search_dtype` is the dtype of tgt and piv.
+ * ------------------------------------------------------------------------ */
+size_t tf_nn_gather_blend_workspace_bytes(int64_t n_tgt, int S, int D, int P);
+
+int tf_nn_gather_blend(const void* tgt, const void* piv, const float* inv_norm,
+                       const void* kf_out, const float* w, const void* resid, void* out,
+                       int K, int n, int S, int D, int P, int kf0, int kf1,
+                       int search_dtype, int in_dtype, int res_dtype, int out_dtype,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
  * PnP feature injection  --  replaces tokenflow_utils.py:87-91:
  *   x viewed as [3, elems_per_branch]:  x[1] = x[0];  x[2] = x[0]   (in place)
  * elem_bytes = bytes per element; elems_per_branch*elem_bytes multiple of 16.

@@ -77,6 +77,9 @@ class FakeOps:
             o = o + residual.float()
         return o.to(out_dtype)
 
+    def propagate(self, tgt, piv, inv_norm, kf_ids, kf_out, w, n, residual, out_dtype):
+        return self.gather_blend(kf_out, self.nn_search(tgt, piv, inv_norm, kf_ids), w, kf_ids, n, residual, out_dtype)
+
     def inject_copy_(self, x):
         self.calls.append(("inject_copy_", tuple(x.shape)))
         return orc.conv_inject_(x)

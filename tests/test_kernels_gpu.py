@@ -370,6 +370,28 @@ def test_gather_blend_dtypes(in_dt, res_dt, out_dt, P):
     assert torch.equal(out.cpu(), ref)
 
 
+@pytest.mark.parametrize("K,n,S,D", [(3, 5, 4096, 320), (3, 2, 1024, 640), (2, 3, 256, 1280), (2, 2, 64, 1280),
+                                     (2, 3, 200, 72)])
+@pytest.mark.parametrize("P", [1, 2])
+def test_propagate_equals_search_then_gather(K, n, S, D, P):
+    """tf_nn_gather_blend (the gather merges the search's per-split candidates itself) must equal
+    tf_nn_search + tf_gather_blend bit for bit -- with the pivot range split (large S) and not."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(31)
+    piv = torch.nn.functional.layer_norm(torch.randn(K, S, D, generator=g, device="cuda"), (D,)).bfloat16()
+    tgt = torch.nn.functional.layer_norm(torch.randn(n * S, D, generator=g, device="cuda"), (D,)).bfloat16()
+    kf_out = torch.randn(3 * K, S, D, generator=g, device="cuda").bfloat16()
+    res = torch.randn(3 * n, S, D, generator=g, device="cuda").bfloat16()
+    inv = ops.pivot_inv_norm(piv)
+    ids = [K - 1, K - 2][:P]
+    w = orc.blend_weights(n, 1).cuda() if P == 2 else None
+    out_dtype = torch.float32 if P == 2 else torch.bfloat16
+    idx = ops.nn_search(tgt, piv, inv, ids)
+    two = ops.gather_blend(kf_out, idx, w, ids, n, res, out_dtype)
+    one = ops.propagate(tgt, piv, inv, ids, kf_out, w, n, res, out_dtype)
+    assert one.dtype == two.dtype and torch.equal(one, two)
+
+
 def test_inject_copy_exact():
     ops = _ops()
     g = torch.Generator().manual_seed(1)

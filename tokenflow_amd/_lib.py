@@ -22,6 +22,8 @@ _SIGNATURES = {
     "tf_nn_search": (_c.c_int, [_c.c_void_p] * 4 + [_c.c_int64] + [_c.c_int] * 6 + [_c.c_void_p, _c.c_size_t,
                                 _c.c_void_p]),
     "tf_gather_blend": (_c.c_int, [_c.c_void_p] * 5 + [_c.c_int] * 10 + [_c.c_void_p]),
+    "tf_nn_gather_blend_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int, _c.c_int]),
+    "tf_nn_gather_blend": (_c.c_int, [_c.c_void_p] * 7 + [_c.c_int] * 11 + [_c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "tf_inject_copy": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p]),
 }
 EXPORTS = tuple(_SIGNATURES)

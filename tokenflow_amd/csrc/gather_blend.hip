@@ -59,9 +59,12 @@ __device__ __forceinline__ void store8(T* p, const float (&f)[8]) {
 
 struct NoRes {};
 
-template <typename TIn, typename TRes, typename TOut, int P>
+// MERGE: the indices come as the search's per-split partial results (tf_nn_gather_blend: no finalize launch
+// in between); every thread of a token merges them itself -- `splits` 8-byte reads, broadcast from cache.
+template <typename TIn, typename TRes, typename TOut, int P, bool MERGE>
 __global__ __launch_bounds__(256) void gather_blend_kernel(const TIn* __restrict__ kf_out,
                                                            const int32_t* __restrict__ idx,
+                                                           const NnPartial* __restrict__ part, int splits,
                                                            const float* __restrict__ w, const TRes* __restrict__ resid,
                                                            TOut* __restrict__ out, int K, int n, int S, int D, int kf0,
                                                            int kf1) {
@@ -75,11 +78,11 @@ __global__ __launch_bounds__(256) void gather_blend_kernel(const TIn* __restrict
     for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
         const int64_t t = g / ppr;
         const int c = (int)(g - t * ppr) * 8;
-        const int i1 = idx[t];
+        const int i1 = MERGE ? nn_merge_partials(part + t, P * nS, splits) : idx[t];
         float w1 = 0.f, w2 = 0.f;
         int i2 = 0;
         if constexpr (P == 2) {
-            i2 = idx[nS + t];
+            i2 = MERGE ? nn_merge_partials(part + nS + t, P * nS, splits) : idx[nS + t];
             w1 = w[(int)(t / S)];
             w2 = __fsub_rn(1.0f, w1);
         }
@@ -120,6 +123,8 @@ __global__ __launch_bounds__(256) void inject_copy_kernel(u32x4* __restrict__ x,
 struct GbArgs {
     const void* kf_out;
     const int32_t* idx;
+    const NnPartial* part;   // alternative to idx: partial results of `splits` pivot-range splits
+    int splits;
     const float* w;
     const void* resid;
     void* out;
@@ -132,14 +137,17 @@ void launch_gb(const GbArgs& a) {
     const int64_t total = (int64_t)a.n * a.S * (a.D >> 3);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    if (a.P == 2)
-        hipLaunchKernelGGL((gather_blend_kernel<TIn, TRes, TOut, 2>), dim3((unsigned)blocks), dim3(256), 0, a.st,
-                           (const TIn*)a.kf_out, a.idx, a.w, (const TRes*)a.resid, (TOut*)a.out, a.K, a.n, a.S, a.D,
-                           a.kf0, a.kf1);
-    else
-        hipLaunchKernelGGL((gather_blend_kernel<TIn, TRes, TOut, 1>), dim3((unsigned)blocks), dim3(256), 0, a.st,
-                           (const TIn*)a.kf_out, a.idx, a.w, (const TRes*)a.resid, (TOut*)a.out, a.K, a.n, a.S, a.D,
-                           a.kf0, a.kf0);
+    auto go = [&](auto kern, int kf1) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, a.st, (const TIn*)a.kf_out, a.idx, a.part,
+                           a.splits, a.w, (const TRes*)a.resid, (TOut*)a.out, a.K, a.n, a.S, a.D, a.kf0, kf1);
+    };
+    if (a.part) {
+        if (a.P == 2) go(gather_blend_kernel<TIn, TRes, TOut, 2, true>, a.kf1);
+        else go(gather_blend_kernel<TIn, TRes, TOut, 1, true>, a.kf0);
+    } else {
+        if (a.P == 2) go(gather_blend_kernel<TIn, TRes, TOut, 2, false>, a.kf1);
+        else go(gather_blend_kernel<TIn, TRes, TOut, 1, false>, a.kf0);
+    }
 }
 
 template <typename TIn, typename TRes>
@@ -175,13 +183,55 @@ extern "C" int tf_gather_blend(const void* kf_out, const int32_t* idx, const flo
            TF_ERR_SHAPE, "tf_gather_blend: K=%d n=%d S=%d D=%d P=%d kf=(%d,%d)", K, n, S, D, P, kf0, kf1);
     TF_ARG(tf_aligned16(kf_out) && tf_aligned16(out) && tf_aligned16(resid), TF_ERR_ALIGN,
            "tf_gather_blend: tensors not 16-byte aligned");
-    GbArgs a{kf_out, idx, w, resid, out, K, n, S, D, P, kf0, kf1, reinterpret_cast<hipStream_t>(stream)};
+    GbArgs a{kf_out, idx, nullptr, 0, w, resid, out, K, n, S, D, P, kf0, kf1, reinterpret_cast<hipStream_t>(stream)};
     switch (in_dtype) {
         case TF_BF16: dispatch_res<__bf16>(a, res_dtype, out_dtype); break;
         case TF_F16: dispatch_res<_Float16>(a, res_dtype, out_dtype); break;
         default: dispatch_res<float>(a, res_dtype, out_dtype); break;
     }
     TF_LAUNCH_CHECK("tf_gather_blend");
+    return 0;
+}
+
+extern "C" size_t tf_nn_gather_blend_workspace_bytes(int64_t n_tgt, int S, int D, int P) {
+    if (n_tgt <= 0 || S <= 0 || D <= 0 || P <= 0) return 0;
+    const size_t b = tf_nn_partials_bytes(n_tgt, S, D, P);
+    return b < 256 ? 256 : b;
+}
+
+extern "C" int tf_nn_gather_blend(const void* tgt, const void* piv, const float* inv_norm, const void* kf_out,
+                                  const float* w, const void* resid, void* out, int K, int n, int S, int D, int P,
+                                  int kf0, int kf1, int search_dtype, int in_dtype, int res_dtype, int out_dtype,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    TF_ARG(tgt && piv && inv_norm && kf_out && out && ws && (P == 1 || w), TF_ERR_NULL,
+           "tf_nn_gather_blend: null pointer");
+    TF_ARG(search_dtype == TF_BF16 || search_dtype == TF_F16, TF_ERR_DTYPE,
+           "tf_nn_gather_blend: search dtype %d (bf16/f16 only)", search_dtype);
+    auto okdt = [](int d) { return d == TF_BF16 || d == TF_F16 || d == TF_F32; };
+    TF_ARG(okdt(in_dtype) && okdt(out_dtype) && (!resid || okdt(res_dtype)), TF_ERR_DTYPE,
+           "tf_nn_gather_blend: dtypes in=%d res=%d out=%d", in_dtype, res_dtype, out_dtype);
+    TF_ARG(K > 0 && n > 0 && S > 0 && D > 0 && D % 8 == 0 && (P == 1 || P == 2) && kf0 >= 0 && kf0 < K &&
+               (P == 1 || (kf1 >= 0 && kf1 < K)),
+           TF_ERR_SHAPE, "tf_nn_gather_blend: K=%d n=%d S=%d D=%d P=%d kf=(%d,%d)", K, n, S, D, P, kf0, kf1);
+    TF_ARG(tf_aligned16(tgt) && tf_aligned16(piv) && tf_aligned16(kf_out) && tf_aligned16(out) &&
+               tf_aligned16(resid) && tf_aligned16(ws),
+           TF_ERR_ALIGN, "tf_nn_gather_blend: tensors not 16-byte aligned");
+    const int64_t n_tgt = (int64_t)n * S;
+    TF_ARG(ws_bytes >= tf_nn_gather_blend_workspace_bytes(n_tgt, S, D, P), TF_ERR_WORKSPACE,
+           "tf_nn_gather_blend: workspace %zu < %zu bytes", ws_bytes,
+           tf_nn_gather_blend_workspace_bytes(n_tgt, S, D, P));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    NnPartial* part = reinterpret_cast<NnPartial*>(ws);
+    int splits = 1;
+    const int rc = tf_nn_search_partials(tgt, piv, inv_norm, part, n_tgt, S, D, P, kf0, kf1, search_dtype, st, &splits);
+    if (rc) return rc;
+    GbArgs a{kf_out, nullptr, part, splits, w, resid, out, K, n, S, D, P, kf0, kf1, st};
+    switch (in_dtype) {
+        case TF_BF16: dispatch_res<__bf16>(a, res_dtype, out_dtype); break;
+        case TF_F16: dispatch_res<_Float16>(a, res_dtype, out_dtype); break;
+        default: dispatch_res<float>(a, res_dtype, out_dtype); break;
+    }
+    TF_LAUNCH_CHECK("tf_nn_gather_blend");
     return 0;
 }
 

@@ -29,11 +29,6 @@
 
 namespace {
 
-struct NnPartial {
-    float v;
-    int i;
-};
-
 constexpr int TM = 128;  // pivots per tile
 // byte offset of 16-B piece `piece` of row `row` in a [rows][BK] 16-bit tile, BK = 64 or 128 (D chunk).
 // 128-B rows: two rows share a 256-B bank row -> XOR by (row >> 1) & 7; 256-B rows: XOR by row & 15.
@@ -446,7 +441,7 @@ static int finalize(const NnPartial* part, int32_t* idx, int64_t total, int spli
 
 template <typename T, int WN, int BK>
 int launch_nn(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, NnPartial* ws, int64_t n_tgt,
-              int S, int D, int P, int kf0, int kf1, hipStream_t st) {
+              int S, int D, int P, int kf0, int kf1, hipStream_t st, bool fin) {
     constexpr int TN = 64 * WN;
     const size_t lds = 2 * (TM + TN) * BK * 2 + 2 * TM * 4 + 2 * TN * 8;
     const NnPlan pl = nn_plan(n_tgt, S, D, P);
@@ -455,15 +450,16 @@ int launch_nn(const void* tgt, const void* piv, const float* inv_norm, int32_t* 
     auto kern = nn_search_kernel<T, WN, BK>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, reinterpret_cast<const typename T::elem*>(tgt),
-                       reinterpret_cast<const typename T::elem*>(piv), inv_norm, idx, splits > 1 ? ws : nullptr, n_tgt,
+                       reinterpret_cast<const typename T::elem*>(piv), inv_norm, idx,
+                       (splits > 1 || !fin) ? ws : nullptr, n_tgt,
                        S, D, kf0, kf1, tps);
     TF_LAUNCH_CHECK("tf_nn_search");
-    return splits > 1 ? finalize(ws, idx, n_tgt * P, splits, st) : 0;
+    return (fin && splits > 1) ? finalize(ws, idx, n_tgt * P, splits, st) : 0;
 }
 
 template <typename T, int DK>
 int launch_nn_rb(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, NnPartial* ws, int64_t n_tgt,
-                 int S, int P, int kf0, int kf1, hipStream_t st) {
+                 int S, int P, int kf0, int kf1, hipStream_t st, bool fin) {
     constexpr int D = 16 * DK;
     const size_t lds = 2 * 32 * (D + 8) * 2 + 2 * 32 * 4;
     const NnPlan pl = nn_plan(n_tgt, S, D, P);
@@ -471,22 +467,22 @@ int launch_nn_rb(const void* tgt, const void* piv, const float* inv_norm, int32_
     dim3 grid((unsigned)pl.panels, (unsigned)P, (unsigned)splits);
     hipLaunchKernelGGL((nn_search_rb_kernel<T, DK>), grid, dim3(256), lds, st,
                        reinterpret_cast<const typename T::elem*>(tgt), reinterpret_cast<const typename T::elem*>(piv),
-                       inv_norm, idx, splits > 1 ? ws : nullptr, n_tgt, S, kf0, kf1, tps);
+                       inv_norm, idx, (splits > 1 || !fin) ? ws : nullptr, n_tgt, S, kf0, kf1, tps);
     TF_LAUNCH_CHECK("tf_nn_search");
-    return splits > 1 ? finalize(ws, idx, n_tgt * P, splits, st) : 0;
+    return (fin && splits > 1) ? finalize(ws, idx, n_tgt * P, splits, st) : 0;
 }
 
 template <typename T>
 int dispatch_nn(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, NnPartial* ws, int64_t n_tgt,
-                int S, int D, int P, int kf0, int kf1, hipStream_t st) {
+                int S, int D, int P, int kf0, int kf1, hipStream_t st, bool fin) {
     const NnPlan pl = nn_plan(n_tgt, S, D, P);
-    if (pl.rb) return launch_nn_rb<T, 20>(tgt, piv, inv_norm, idx, ws, n_tgt, S, P, kf0, kf1, st);
+    if (pl.rb) return launch_nn_rb<T, 20>(tgt, piv, inv_norm, idx, ws, n_tgt, S, P, kf0, kf1, st, fin);
     // 128-target panels for all but the small target sets (nn_plan), else 64-target panels
-    if (pl.wide) return launch_nn<T, 2, 64>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st);
+    if (pl.wide) return launch_nn<T, 2, 64>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin);
     // few workgroups and a long contraction: latency-bound per iteration -> 128-wide D chunks
     if (pl.panels * P * pl.splits <= 512 && D >= 512)
-        return launch_nn<T, 1, 128>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st);
-    return launch_nn<T, 1, 64>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st);
+        return launch_nn<T, 1, 128>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin);
+    return launch_nn<T, 1, 64>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin);
 }
 
 }  // namespace
@@ -529,6 +525,18 @@ extern "C" int tf_nn_search(const void* tgt, const void* piv, const float* inv_n
            "tf_nn_search: workspace %zu < %zu bytes", ws_bytes, tf_nn_search_workspace_bytes(n_tgt, S, D, P));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     NnPartial* part = reinterpret_cast<NnPartial*>(ws);
-    return dtype == TF_BF16 ? dispatch_nn<BF16>(tgt, piv, inv_norm, idx, part, n_tgt, S, D, P, kf0, kf1, st)
-                            : dispatch_nn<F16>(tgt, piv, inv_norm, idx, part, n_tgt, S, D, P, kf0, kf1, st);
+    return dtype == TF_BF16 ? dispatch_nn<BF16>(tgt, piv, inv_norm, idx, part, n_tgt, S, D, P, kf0, kf1, st, true)
+                            : dispatch_nn<F16>(tgt, piv, inv_norm, idx, part, n_tgt, S, D, P, kf0, kf1, st, true);
+}
+
+int tf_nn_search_partials(const void* tgt, const void* piv, const float* inv_norm, NnPartial* part, int64_t n_tgt,
+                          int S, int D, int P, int kf0, int kf1, int dtype, hipStream_t st, int* splits) {
+    *splits = nn_plan(n_tgt, S, D, P).splits;
+    return dtype == TF_BF16
+               ? dispatch_nn<BF16>(tgt, piv, inv_norm, nullptr, part, n_tgt, S, D, P, kf0, kf1, st, false)
+               : dispatch_nn<F16>(tgt, piv, inv_norm, nullptr, part, n_tgt, S, D, P, kf0, kf1, st, false);
+}
+
+size_t tf_nn_partials_bytes(int64_t n_tgt, int S, int D, int P) {
+    return (size_t)nn_plan(n_tgt, S, D, P).splits * P * n_tgt * sizeof(NnPartial);
 }

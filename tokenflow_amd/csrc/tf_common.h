@@ -45,6 +45,26 @@ __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4
 template <typename T>
 __device__ __forceinline__ float to_f32(T x) { return (float)x; }
 
+// ---- nearest-neighbour partial results (nn_search.hip -> gather_blend.hip) ----------------------
+// One (best score, index) pair per (pivot-range split, keyframe, target); merged in ascending split
+// order with a strict '>' so the first index wins ties.
+struct NnPartial {
+    float v;
+    int i;
+};
+__device__ __forceinline__ int nn_merge_partials(const NnPartial* part, int64_t stride, int splits) {
+    NnPartial b = part[0];
+    for (int s = 1; s < splits; ++s) {
+        const NnPartial c = part[(int64_t)s * stride];
+        if (c.v > b.v) b = c;
+    }
+    return b.i;
+}
+// Search only (no finalize launch): partial results [splits][P][n_tgt] into `part`; arguments already validated.
+int tf_nn_search_partials(const void* tgt, const void* piv, const float* inv_norm, NnPartial* part, int64_t n_tgt,
+                          int S, int D, int P, int kf0, int kf1, int dtype, hipStream_t st, int* splits);
+size_t tf_nn_partials_bytes(int64_t n_tgt, int S, int D, int P);
+
 // ---- host-side error plumbing ------------------------------------------------
 void tf_set_error(const char* fmt, ...);
 

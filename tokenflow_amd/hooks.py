@@ -299,16 +299,16 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
                 if self.batch_idx > 0:
                     batch_idxs.append(self.batch_idx - 1)
                 tgt = norm_hidden_states[0].reshape(n_frames * sequence_length, dim).to(self._tf_pivots.dtype)
-                idx = ops.nn_search(tgt, self._tf_pivots, self._tf_pivot_inv_norm, batch_idxs)
-                # 361-397: gather (same indices for the 3 branches), blend, residual -- one launch.
+                # 361-397: gather (same indices for the 3 branches), blend, residual -- fused with the search.
                 # dtype follows torch promotion in the reference: the blend is fp32 (w1 is fp32, 385-388),
                 # chunk 0 keeps the cached dtype (390); then `attn_output + hidden_states` (397).
                 kf = self.kf_attn_output
                 blend_dtype = torch.float32 if len(batch_idxs) == 2 else kf.dtype
                 out_dtype = torch.promote_types(blend_dtype, hidden_states.dtype)
                 w = _blend_weights(n_frames, kf.device) if len(batch_idxs) == 2 else None
-                hidden_states = ops.gather_blend(kf, idx, w, batch_idxs, n_frames,
-                                                 hidden_states.reshape(batch_size, sequence_length, dim), out_dtype)
+                hidden_states = ops.propagate(tgt, self._tf_pivots, self._tf_pivot_inv_norm, batch_idxs, kf, w,
+                                              n_frames, hidden_states.reshape(batch_size, sequence_length, dim),
+                                              out_dtype)
 
             if self.attn2 is not None:
                 norm_hidden_states = (

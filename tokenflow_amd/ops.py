@@ -136,6 +136,34 @@ def gather_blend(kf_out: torch.Tensor, idx: torch.Tensor, w: Optional[torch.Tens
     return out
 
 
+def propagate(tgt: torch.Tensor, piv: torch.Tensor, inv_norm: torch.Tensor, kf_ids: Sequence[int],
+              kf_out: torch.Tensor, w: Optional[torch.Tensor], n: int, residual: Optional[torch.Tensor],
+              out_dtype: torch.dtype) -> torch.Tensor:
+    """nn_search + gather_blend of one chunk in one call (tokenflow_utils.py:329-397): same arguments, same
+    results bit for bit, one launch less (the gather merges the search's per-split candidates itself)."""
+    _need_gpu(tgt, piv, inv_norm, kf_out, w, residual)
+    lib = _lib.load()
+    tgt, piv, kf_out = tgt.contiguous(), piv.contiguous(), kf_out.contiguous()
+    K, S, D = piv.shape
+    n_tgt = tgt.shape[0]
+    P = len(kf_ids)
+    if (tgt.dtype != piv.dtype or tgt.shape[1] != D or P not in (1, 2) or any(not 0 <= i < K for i in kf_ids)
+            or n_tgt != n * S or kf_out.shape != (3 * K, S, D)):
+        raise ValueError("propagate: bad arguments")
+    if residual is not None:
+        residual = residual.contiguous()
+    out = torch.empty(3 * n, S, D, dtype=out_dtype, device=kf_out.device)
+    ws = _workspace(lib.tf_nn_gather_blend_workspace_bytes(n_tgt, S, D, P), tgt.device, "nn")
+    _lib.check(lib.tf_nn_gather_blend(tgt.data_ptr(), piv.data_ptr(), inv_norm.data_ptr(), kf_out.data_ptr(),
+                                      w.data_ptr() if w is not None else 0,
+                                      residual.data_ptr() if residual is not None else 0, out.data_ptr(),
+                                      K, n, S, D, P, int(kf_ids[0]), int(kf_ids[1]) if P == 2 else 0,
+                                      _DT[tgt.dtype], _DT[kf_out.dtype],
+                                      _DT[residual.dtype] if residual is not None else 0, _DT[out_dtype],
+                                      ws.data_ptr(), ws.numel(), _stream()), "tf_nn_gather_blend")
+    return out
+
+
 def inject_copy_(x: torch.Tensor) -> torch.Tensor:
     """In place: x[n:2n] = x[:n]; x[2n:] = x[:n] with n = len(x)//3 (tokenflow_utils.py:87-91)."""
     _need_gpu(x)

@@ -214,7 +214,7 @@ class FrameShard:
         c = self.kf0 + j
         o = 1 if self.world > 1 else 0                   # halo slot offset
         ids = [j + o] if c == 0 else [j + o, j + o - 1]  # slots of keyframes [c, c-1] (tokenflow_utils.py:331-333)
-        idx = ops.nn_search(tgt, piv_ext, inv_ext, ids)
         blend_dtype = out_dtype_two if len(ids) == 2 else kf_out_ext.dtype
         out_dtype = torch.promote_types(blend_dtype, residual.dtype) if residual is not None else blend_dtype
-        return ops.gather_blend(kf_out_ext, idx, w if len(ids) == 2 else None, ids, n, residual, out_dtype)
+        return ops.propagate(tgt, piv_ext, inv_ext, ids, kf_out_ext, w if len(ids) == 2 else None, n, residual,
+                             out_dtype)
