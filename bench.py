@@ -121,9 +121,10 @@ def usable_cores():
 
 def cpu_baseline(cfg, levels):
     """Time the CPU oracle on a bounded sample and extrapolate to one full step.
-    Sample: per level, ONE (frame, head) pair of the bank problem (its queries against the full
-    K*S-key bank) and of the source problem, ONE chunk of NN search (two keyframes) and ONE
-    chunk of gather/blend; scaled by heads x frames x branches, chunk count and block count."""
+    Sample: per level, ONE frame (all heads unless the score matrices pass 16 GB, batched as the reference's bmm is) of the bank problem
+    (its queries against the full K*S-key bank) and of the source problem, ONE chunk of NN search (two
+    keyframes) and ONE chunk of gather/blend; scaled by heads x frames x branches, chunk count and block
+    count.  About 10 s of CPU work at cfg2 (each piece runs three times: warm-up + best of two)."""
     from oracle import tokenflow_oracle as orc
     torch.set_num_threads(usable_cores())
     K, n, C = cfg.K, cfg.chunk, cfg.K
@@ -146,15 +147,18 @@ def cpu_baseline(cfg, levels):
         nblk = sum(1 for l, _ in workload.BLOCKS if l == lvl)
         if lvl not in levels:
             continue
-        q = torch.randn(1, S, d, generator=g)
-        kb, vb = torch.randn(1, K * S, d, generator=g), torch.randn(1, K * S, d, generator=g)
+        # heads in the sample: all of them while scores + softmax (2 x hs*S*K*S fp32) stay under 16 GB of host
+        # memory (8.6 GB at cfg2 level 0; the reference materialises the same matrices, tokenflow_utils.py:173-179)
+        hs = max(1, min(h, int(16e9 // (8.0 * S * K * S))))
+        q = torch.randn(hs, S, d, generator=g)
+        kb, vb = torch.randn(hs, K * S, d, generator=g), torch.randn(hs, K * S, d, generator=g)
 
         def attn(kk, vv):
             sim = torch.bmm(q, kk.transpose(-1, -2)) * d ** -0.5        # tokenflow_utils.py:173-175
             return torch.bmm(sim.softmax(dim=-1), vv)                   # :177-179
         t_bank, _ = timed(lambda: attn(kb, vb))
         t_src, _ = timed(lambda: attn(kb[:, :S], vb[:, :S]))
-        t_attn = K * h * (2 * t_bank + t_src)
+        t_attn = K * (h / hs) * (2 * t_bank + t_src)
         piv = torch.randn(K, S, D, generator=g)
         tgt = torch.randn(n, S, D, generator=g)
         kf_out = torch.randn(3 * K, S, D, generator=g)
@@ -167,7 +171,7 @@ def cpu_baseline(cfg, levels):
         parts.append(f"L{lvl}: bank {t_bank:.2f}s src {t_src:.2f}s nn {t_nn2:.2f}s gather {t_gb2:.2f}s")
     return dict(value=cfg.frames / total, unit="frames/s", cores=torch.get_num_threads(), kind="port",
                 sample=("oracle (fp32 torch CPU restatement of the reference hooks) timed per level on one "
-                        "(frame,head) bank+source attention problem, one 2-keyframe NN-search chunk and one "
+                        "frame (all heads, memory permitting) of the bank+source attention, one 2-keyframe NN-search chunk and one "
                         "gather/blend chunk, extrapolated by heads*frames*branches, chunks and blocks to a full "
                         f"step ({total:.1f} s/step extrapolated from {t_spent:.1f} s of best-of-2 samples; " + "; ".join(parts) + ")"))
 
