@@ -153,6 +153,22 @@ int tf_nn_gather_blend(const void* tgt, const void* piv, const float* inv_norm,
                        void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Row LayerNorm producer  --  the `norm1` call of TokenFlowBlock.forward
+ * (tokenflow_utils.py:313-323; also norm2 / norm3 of the same forward, 399-417)
+ * when the block runs in 16 bit:  out[r] = (x[r] - mean) / sqrt(var + eps) * gamma + beta
+ * with fp32 statistics (biased variance, as torch) and ONE rounding to out_dtype,
+ * instead of torch's autocast sequence cast-up / fp32 norm / cast-down.
+ *   x      : [rows, D]  (in_dtype)      D multiple of 8, D <= 2048
+ *   gamma, beta : [D] (w_dtype) or NULL (= 1 / 0)
+ *   out    : [rows, D]  (out_dtype)
+ *   inv_norm : float [rows] or NULL:  1 / ||out[r]||_2 of the ROUNDED output row -- what
+ *              tf_pivot_inv_norm would compute from the stored pivots (util.py:67).
+ * ------------------------------------------------------------------------ */
+int tf_layer_norm(const void* x, const void* gamma, const void* beta, void* out, float* inv_norm,
+                  int64_t rows, int D, float eps, int in_dtype, int w_dtype, int out_dtype,
+                  void* stream);
+
+/* ------------------------------------------------------------------------
  * PnP feature injection  --  replaces tokenflow_utils.py:87-91:
  *   x viewed as [3, elems_per_branch]:  x[1] = x[0];  x[2] = x[0]   (in place)
  * elem_bytes = bytes per element; elems_per_branch*elem_bytes multiple of 16.

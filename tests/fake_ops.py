@@ -77,6 +77,11 @@ class FakeOps:
             o = o + residual.float()
         return o.to(out_dtype)
 
+    def layer_norm(self, x, weight, bias, eps, out_dtype, want_inv_norm=False):
+        y = torch.nn.functional.layer_norm(x.float(), (x.shape[-1],), None if weight is None else weight.float(),
+                                           None if bias is None else bias.float(), eps).to(out_dtype)
+        return y, (1.0 / y.float().norm(dim=-1) if want_inv_norm else None)
+
     def propagate(self, tgt, piv, inv_norm, kf_ids, kf_out, w, n, residual, out_dtype):
         return self.gather_blend(kf_out, self.nn_search(tgt, piv, inv_norm, kf_ids), w, kf_ids, n, residual, out_dtype)
 

@@ -202,3 +202,58 @@ def test_hooks_on_gpu_match_cpu_reference_numerics():
         assert a.shape == b.shape
         err = float((a - b).abs().max())
         assert err < 2e-2, f"pass {i}: {err}"
+
+
+def test_hooks_16bit_block_uses_fused_norm_and_matches_module_norm():
+    """A 16-bit block takes the fused LayerNorm producer (row f2) for norm1/norm2/norm3 and the pivots' inverse
+    norms; the outputs stay within 16-bit rounding of the same hooks with the module LayerNorms."""
+    import tokenflow_utils as tfu
+    from tests import fake_diffusers as fd
+    from tokenflow_amd import hooks
+
+    torch.manual_seed(0)
+    blk = fd.BasicTransformerBlock(320, 8, cross_dim=32).eval()
+    holder = torch.nn.Module()
+    holder.unet = torch.nn.Module()
+    holder.unet.blk = blk
+    holder.cuda().bfloat16()
+    blk.attn1.forward = hooks._make_sa_forward(blk.attn1, pnp=True)
+    hooks._set_schedule(blk.attn1, [5])
+    blk.attn1.t = 5
+    tfu.set_tokenflow(holder)
+    K, n, S = 3, 2, 192
+    g = torch.Generator().manual_seed(1)
+    x_piv = torch.randn(3 * K, S, 320, generator=g).cuda().bfloat16()
+    enc, enc_n = (torch.randn(3 * m, 7, 32, generator=g).cuda().bfloat16() for m in (K, n))
+    perm = torch.randperm(S, generator=g)
+    src = x_piv.view(3, K, S, 320)[0, 1][perm][None].repeat(n, 1, 1)
+    chunk = torch.cat([src, torch.randn(2 * n, S, 320, generator=g).cuda().bfloat16()])
+
+    def run():   # under autocast, as the reference runs its UNet passes (run_tokenflow_pnp.py:220)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            tfu.register_pivotal(holder, True)
+            a = blk(x_piv, encoder_hidden_states=enc)
+            inv = blk._tf_pivot_inv_norm.clone()
+            tfu.register_pivotal(holder, False)
+            tfu.register_batch_idx(holder, 1)
+            b = blk(chunk, encoder_hidden_states=enc_n)
+        return a.float(), b.float(), inv
+
+    calls = []
+    real = hooks.ops.layer_norm
+    spy = lambda *a, **k: (calls.append(a[0].shape), real(*a, **k))[1]
+    hooks.ops.layer_norm = spy
+    try:
+        fused = run()
+    finally:
+        hooks.ops.layer_norm = real
+    assert len(calls) == 6                         # norm1, norm2, norm3 in both passes
+    keep = hooks._fused_norm_dtype
+    hooks._fused_norm_dtype = lambda mod, x: None
+    try:
+        plain = run()
+    finally:
+        hooks._fused_norm_dtype = keep
+    assert torch.allclose(fused[2], plain[2], rtol=1e-5)
+    for f, p in zip(fused[:2], plain[:2]):
+        assert f.shape == p.shape and float((f - p).abs().max()) < 6e-2 * float(p.abs().max().clamp(min=1.0))

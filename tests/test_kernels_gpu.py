@@ -400,3 +400,46 @@ def test_inject_copy_exact():
         ref = orc.conv_inject_(x.clone())
         out = ops.inject_copy_(x.cuda())
         assert torch.equal(out.cpu(), ref)
+
+
+# --------------------------------------------------------------------------- layer norm (row f2)
+
+
+@pytest.mark.parametrize("rows,D", [(4096, 320), (515, 640), (37, 1280), (5, 72), (3, 2048)])
+@pytest.mark.parametrize("in_dt,w_dt,out_dt", [
+    (torch.bfloat16, torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32, torch.bfloat16),
+    (torch.float32, torch.float32, torch.bfloat16), (torch.float16, torch.float16, torch.float16),
+    (torch.float32, None, torch.float32), (torch.bfloat16, torch.float32, torch.float32)])
+def test_layer_norm_vs_torch_fp32(rows, D, in_dt, w_dt, out_dt):
+    """tf_layer_norm against torch's fp32 layer_norm of the same (already rounded) input: fp32 output within
+    2e-6 (relative to max(1,|ref|)), 16-bit output within one rounding of the fp32 result; the inverse norms
+    are those of the ROUNDED output rows (what tf_pivot_inv_norm computes from the stored pivots)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows * 7 + D)
+    x = (torch.randn(rows, D, generator=g) * 3 + 0.5).to(in_dt)
+    w = (1 + 0.2 * torch.randn(D, generator=g)).to(w_dt) if w_dt is not None else None
+    b = (0.1 * torch.randn(D, generator=g)).to(w_dt) if w_dt is not None else None
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), None if w is None else w.float(),
+                                         None if b is None else b.float(), 1e-5)
+    out, inv = ops.layer_norm(x.cuda(), None if w is None else w.cuda(), None if b is None else b.cuda(), 1e-5,
+                              out_dt, want_inv_norm=True)
+    assert out.dtype == out_dt and out.shape == x.shape and inv.shape == (rows,)
+    got = out.float().cpu()
+    eps = {torch.float32: 2e-6, torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[out_dt]
+    bound = eps * ref.abs().clamp(min=1.0) + (4e-6 if out_dt != torch.float32 else 0.0)
+    assert bool(((got - ref).abs() <= bound).all()), float(((got - ref).abs() - bound).max())
+    inv_ref = 1.0 / got.norm(dim=-1)
+    assert torch.allclose(inv.cpu(), inv_ref, rtol=2e-6, atol=0)
+    same = ops.pivot_inv_norm(out) if out_dt != torch.float32 else None
+    if same is not None:          # the producer's side output and the stand-alone kernel agree
+        assert torch.allclose(inv, same, rtol=2e-6, atol=0)
+
+
+def test_layer_norm_argument_errors():
+    ops = _ops()
+    from tokenflow_amd._lib import TokenflowHipError
+    x = torch.randn(4, 2056, device="cuda").bfloat16()
+    with pytest.raises(TokenflowHipError):
+        ops.layer_norm(x, None, None, 1e-5, torch.bfloat16)          # D > 2048
+    with pytest.raises(TokenflowHipError):
+        ops.layer_norm(x[:, :12], None, None, 1e-5, torch.bfloat16)  # D % 8

@@ -1,0 +1,174 @@
+// Row LayerNorm producer of the hot path: replaces the `norm1` call of
+// TokenFlowBlock.forward (tokenflow_utils.py:313-323) -- and norm2/norm3 of the same forward -- when the
+// block runs in 16 bit.  Under autocast torch evaluates layer_norm in fp32: a cast kernel up, the norm,
+// and a cast down in front of the next Linear, 20 bytes of HBM traffic per element where 4 are needed.
+// Here: one pass, 16-bit (or fp32) in, fp32 statistics, one rounding to the output type, and -- for the
+// pivots of the NN search -- 1/||y||_2 of the ROUNDED output row as a side product (what
+// tf_pivot_inv_norm computes from the stored pivots, util.py:67), so the pivots are never re-read.
+// One wave per row, the row lives in registers (D <= 2048); HBM-bound.
+#include "tf_common.h"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ void ln_load8(const T* p, float (&f)[8]) {
+    if constexpr (sizeof(T) == 4) {
+        const u32x4 a = ld16(p), b = ld16(p + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[i] = __uint_as_float(a[i]);
+            f[4 + i] = __uint_as_float(b[i]);
+        }
+    } else {
+        typedef T v8 __attribute__((ext_vector_type(8)));
+        const v8 v = __builtin_bit_cast(v8, ld16(p));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+    }
+}
+
+// stores 8 values rounded to T and returns the sum of squares of the ROUNDED values
+template <typename T>
+__device__ __forceinline__ float ln_store8(T* p, const float (&f)[8]) {
+    float ss = 0.f;
+    if constexpr (sizeof(T) == 4) {
+        u32x4 a, b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i] = __float_as_uint(f[i]);
+            b[i] = __float_as_uint(f[4 + i]);
+        }
+        st16(p, a);
+        st16(p + 4, b);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ss = fmaf(f[i], f[i], ss);
+    } else {
+        typedef T v8 __attribute__((ext_vector_type(8)));
+        v8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[i] = (T)f[i];
+            ss = fmaf((float)v[i], (float)v[i], ss);
+        }
+        st16(p, __builtin_bit_cast(u32x4, v));
+    }
+    return ss;
+}
+
+__device__ __forceinline__ void ln_load_w(const void* w, int w_dtype, int col, float dflt, float (&f)[8]) {
+    if (w == nullptr) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = dflt;
+    } else if (w_dtype == TF_F32) {
+        ln_load8(reinterpret_cast<const float*>(w) + col, f);
+    } else if (w_dtype == TF_BF16) {
+        ln_load8(reinterpret_cast<const __bf16*>(w) + col, f);
+    } else {
+        ln_load8(reinterpret_cast<const _Float16*>(w) + col, f);
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
+constexpr int LN_MAXP = 4;   // 16-B pieces per lane: D <= 64 * 8 * 4 = 2048
+
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void layer_norm_kernel(const TIn* __restrict__ x, const void* __restrict__ gamma,
+                                                         const void* __restrict__ beta, TOut* __restrict__ out,
+                                                         float* __restrict__ inv_norm, int64_t rows, int D, float eps,
+                                                         int w_dtype) {
+    const int lane = threadIdx.x & 63;
+    const int pieces = D >> 3;
+    const float inv_d = 1.0f / (float)D;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        const TIn* xr = x + r * D;
+        float v[LN_MAXP][8];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXP; ++j) {
+            const int p = lane + 64 * j;
+            if (p < pieces) {
+                ln_load8(xr + p * 8, v[j]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += v[j][i];
+            }
+        }
+        const float mean = wave_sum(s) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXP; ++j)
+            if (lane + 64 * j < pieces) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float c = v[j][i] - mean;
+                    q = fmaf(c, c, q);
+                }
+            }
+        const float rstd = 1.0f / __builtin_sqrtf(wave_sum(q) * inv_d + eps);   // biased variance, as torch
+        float ss = 0.f;
+        TOut* orow = out + r * D;
+#pragma unroll
+        for (int j = 0; j < LN_MAXP; ++j) {
+            const int p = lane + 64 * j;
+            if (p < pieces) {
+                float g[8], b[8], y[8];
+                ln_load_w(gamma, w_dtype, p * 8, 1.f, g);
+                ln_load_w(beta, w_dtype, p * 8, 0.f, b);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) y[i] = fmaf((v[j][i] - mean) * rstd, g[i], b[i]);
+                ss += ln_store8(orow + p * 8, y);
+            }
+        }
+        if (inv_norm != nullptr) {
+            ss = wave_sum(ss);
+            if (lane == 0) inv_norm[r] = 1.0f / __builtin_sqrtf(ss);
+        }
+    }
+}
+
+template <typename TIn, typename TOut>
+void launch_ln(const void* x, const void* gamma, const void* beta, void* out, float* inv_norm, int64_t rows, int D,
+               float eps, int w_dtype, hipStream_t st) {
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL((layer_norm_kernel<TIn, TOut>), dim3((unsigned)blocks), dim3(256), 0, st,
+                       reinterpret_cast<const TIn*>(x), gamma, beta, reinterpret_cast<TOut*>(out), inv_norm, rows, D,
+                       eps, w_dtype);
+}
+
+template <typename TIn>
+void dispatch_ln_out(int out_dtype, const void* x, const void* gamma, const void* beta, void* out, float* inv_norm,
+                     int64_t rows, int D, float eps, int w_dtype, hipStream_t st) {
+    switch (out_dtype) {
+        case TF_BF16: launch_ln<TIn, __bf16>(x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st); break;
+        case TF_F16: launch_ln<TIn, _Float16>(x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st); break;
+        default: launch_ln<TIn, float>(x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st); break;
+    }
+}
+
+}  // namespace
+
+extern "C" int tf_layer_norm(const void* x, const void* gamma, const void* beta, void* out, float* inv_norm,
+                             int64_t rows, int D, float eps, int in_dtype, int w_dtype, int out_dtype,
+                             void* stream) {
+    TF_ARG(x && out, TF_ERR_NULL, "tf_layer_norm: null pointer");
+    auto okdt = [](int d) { return d == TF_BF16 || d == TF_F16 || d == TF_F32; };
+    TF_ARG(okdt(in_dtype) && okdt(out_dtype) && ((!gamma && !beta) || okdt(w_dtype)), TF_ERR_DTYPE,
+           "tf_layer_norm: dtypes in=%d w=%d out=%d", in_dtype, w_dtype, out_dtype);
+    TF_ARG(rows > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * LN_MAXP, TF_ERR_SHAPE,
+           "tf_layer_norm: rows=%lld D=%d (D %% 8 == 0, D <= %d)", (long long)rows, D, 64 * 8 * LN_MAXP);
+    TF_ARG(tf_aligned16(x) && tf_aligned16(out) && tf_aligned16(gamma) && tf_aligned16(beta), TF_ERR_ALIGN,
+           "tf_layer_norm: tensors not 16-byte aligned");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (in_dtype) {
+        case TF_BF16: dispatch_ln_out<__bf16>(out_dtype, x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st); break;
+        case TF_F16: dispatch_ln_out<_Float16>(out_dtype, x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st); break;
+        default: dispatch_ln_out<float>(out_dtype, x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st); break;
+    }
+    TF_LAUNCH_CHECK("tf_layer_norm");
+    return 0;
+}

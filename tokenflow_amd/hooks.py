@@ -251,6 +251,30 @@ def _blend_weights(n: int, device) -> torch.Tensor:
     return w
 
 
+def _fused_norm_dtype(mod: torch.nn.Module, x: torch.Tensor):
+    """The 16-bit dtype in which a plain LayerNorm of the block can be produced directly by
+    `ops.layer_norm` (one pass instead of torch's autocast sequence cast-up / fp32 norm / cast-down in front
+    of the next Linear), or None: keep the module call (fp32 models, AdaLayerNorm, CPU tensors)."""
+    D = x.shape[-1]
+    if (type(mod) is not torch.nn.LayerNorm or not x.is_cuda or tuple(mod.normalized_shape) != (D,)
+            or D % 8 or D > 2048 or x.dtype not in (torch.float32, torch.bfloat16, torch.float16)):
+        return None
+    if torch.is_autocast_enabled("cuda"):
+        dt = torch.get_autocast_dtype("cuda")
+        return dt if dt in (torch.bfloat16, torch.float16) else None
+    if x.dtype != torch.float32 and (mod.weight is None or mod.weight.dtype == x.dtype):
+        return x.dtype
+    return None
+
+
+def _block_norm(mod: torch.nn.Module, x: torch.Tensor, want_inv_norm: bool = False):
+    """(LayerNorm(x), 1/||row|| or None) through the fused kernel when it applies, else the module itself."""
+    dt = _fused_norm_dtype(mod, x)
+    if dt is None:
+        return mod(x), None
+    return ops.layer_norm(x, mod.weight, mod.bias, mod.eps, dt, want_inv_norm)
+
+
 def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[torch.nn.Module]:
     """tokenflow_utils.py:296-429."""
 
@@ -263,13 +287,14 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
             n_frames = batch_size // 3
             hidden_states = hidden_states.view(3, n_frames, sequence_length, dim)
 
+            norm_inv = None
             if self.use_ada_layer_norm:
                 norm_hidden_states = self.norm1(hidden_states, timestep)
             elif self.use_ada_layer_norm_zero:
                 norm_hidden_states, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.norm1(
                     hidden_states, timestep, class_labels, hidden_dtype=hidden_states.dtype)
-            else:
-                norm_hidden_states = self.norm1(hidden_states)
+            else:   # row f2: LayerNorm emits the 16-bit rows the kernels read (+ the pivots' inverse norms)
+                norm_hidden_states, norm_inv = _block_norm(self.norm1, hidden_states, bool(self.pivotal_pass))
             norm_hidden_states = norm_hidden_states.view(3, n_frames, sequence_length, dim)
 
             cross_attention_kwargs = cross_attention_kwargs if cross_attention_kwargs is not None else {}
@@ -278,7 +303,8 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
                 self.pivot_hidden_states = norm_hidden_states
                 src = norm_hidden_states[0]
                 self._tf_pivots = src.to(ops.compute_dtype(src)).contiguous()       # [K,S,D] 16-bit
-                self._tf_pivot_inv_norm = ops.pivot_inv_norm(self._tf_pivots)       # [K,S] fp32
+                self._tf_pivot_inv_norm = (norm_inv.view(3, n_frames, sequence_length)[0] if norm_inv is not None
+                                           else ops.pivot_inv_norm(self._tf_pivots))   # [K,S] fp32
                 self.attn_output = self.attn1(
                     norm_hidden_states.view(batch_size, sequence_length, dim),
                     encoder_hidden_states=encoder_hidden_states if self.only_cross_attention else None,
@@ -312,12 +338,13 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
 
             if self.attn2 is not None:
                 norm_hidden_states = (
-                    self.norm2(hidden_states, timestep) if self.use_ada_layer_norm else self.norm2(hidden_states))
+                    self.norm2(hidden_states, timestep) if self.use_ada_layer_norm
+                    else _block_norm(self.norm2, hidden_states)[0])
                 attn_output = self.attn2(norm_hidden_states, encoder_hidden_states=encoder_hidden_states,
                                          attention_mask=encoder_attention_mask, **cross_attention_kwargs)
                 hidden_states = attn_output + hidden_states
 
-            norm_hidden_states = self.norm3(hidden_states)
+            norm_hidden_states = _block_norm(self.norm3, hidden_states)[0]
             if self.use_ada_layer_norm_zero:
                 norm_hidden_states = norm_hidden_states * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
             ff_output = self.ff(norm_hidden_states)

@@ -136,6 +136,31 @@ def gather_blend(kf_out: torch.Tensor, idx: torch.Tensor, w: Optional[torch.Tens
     return out
 
 
+def layer_norm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], eps: float,
+               out_dtype: torch.dtype, want_inv_norm: bool = False):
+    """LayerNorm over the last dim of x [..., D] (fp32 statistics, one rounding to out_dtype) and, on request,
+    1/||row||_2 of the rounded output rows (fp32 [...]).  Returns (out, inv_norm or None)."""
+    _need_gpu(x, weight, bias)
+    lib = _lib.load()
+    x = x.contiguous()
+    D = x.shape[-1]
+    rows = x.numel() // D
+    if weight is not None and bias is not None and weight.dtype != bias.dtype:
+        bias = bias.to(weight.dtype)
+    wt = weight if weight is not None else bias
+    if wt is not None and wt.dtype not in _DT:
+        raise TypeError(f"layer_norm: weight dtype {wt.dtype}")
+    weight = weight.contiguous() if weight is not None else None
+    bias = bias.contiguous() if bias is not None else None
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    inv = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device) if want_inv_norm else None
+    _lib.check(lib.tf_layer_norm(x.data_ptr(), weight.data_ptr() if weight is not None else 0,
+                                 bias.data_ptr() if bias is not None else 0, out.data_ptr(),
+                                 inv.data_ptr() if inv is not None else 0, rows, D, float(eps), _DT[x.dtype],
+                                 _DT[wt.dtype] if wt is not None else 0, _DT[out_dtype], _stream()), "tf_layer_norm")
+    return out, inv
+
+
 def propagate(tgt: torch.Tensor, piv: torch.Tensor, inv_norm: torch.Tensor, kf_ids: Sequence[int],
               kf_out: torch.Tensor, w: Optional[torch.Tensor], n: int, residual: Optional[torch.Tensor],
               out_dtype: torch.dtype) -> torch.Tensor:

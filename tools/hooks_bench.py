@@ -1,0 +1,91 @@
+#!/usr/bin/env python
+"""Time one denoising step THROUGH THE DROP-IN HOOK API (tokenflow_utils.register_* / set_tokenflow on
+duck-typed diffusers blocks, tests/fake_diffusers.py) at a BASELINE geometry, with the layers that are not
+part of the path (q/k/v/out projections, cross-attention, feed-forward) replaced by identities, so that what
+is timed is the hook layer itself: norm1, dtype casts, Python, and the HIP ops.  Compare with bench.py, which
+calls the ops directly on pre-made tensors.
+
+    python tools/hooks_bench.py [cfg2] [steps]
+"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import tokenflow_utils as tfu  # noqa: E402
+from tests import fake_diffusers as fd  # noqa: E402
+from tokenflow_amd import workload  # noqa: E402
+
+
+class _Id(torch.nn.Module):
+    def forward(self, x, *a, **k):
+        return x
+
+
+def build(cfg, dev, dtype):
+    holder = torch.nn.Module()
+    holder.unet = torch.nn.Module()
+    blocks = []
+    for i, (lvl, injected) in enumerate(workload.BLOCKS):
+        S, D, h = cfg.levels[lvl]
+        blk = fd.BasicTransformerBlock(D, h, cross_dim=32)
+        blk.attn1.to_q, blk.attn1.to_k, blk.attn1.to_v = _Id(), _Id(), _Id()
+        blk.attn1.to_out = torch.nn.ModuleList([_Id(), _Id()])
+        blk.attn2 = None
+        blk.ff = _Id()
+        setattr(holder.unet, f"blk{i}", blk)
+        blocks.append((blk, lvl, injected))
+    holder.to(dev).to(dtype).eval()
+    return holder, blocks
+
+
+def main():
+    cfg = workload.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    dev, dtype = torch.device("cuda"), torch.bfloat16
+    holder, blocks = build(cfg, dev, dtype)
+    from tokenflow_amd import hooks
+    for blk, lvl, injected in blocks:       # what register_extended_attention_pnp does, per block
+        blk.attn1.forward = hooks._make_sa_forward(blk.attn1, pnp=True)
+        hooks._set_schedule(blk.attn1, [5] if injected else [])
+        blk.attn1.t = 5
+    tfu.set_tokenflow(holder)
+    K, n = cfg.K, cfg.chunk
+    g = torch.Generator(device=dev).manual_seed(0)
+    xs_piv = [torch.randn(3 * K, cfg.levels[l][0], cfg.levels[l][1], generator=g, device=dev, dtype=dtype)
+              for _, l, _ in blocks]
+    xs_chk = [torch.randn(3 * n, cfg.levels[l][0], cfg.levels[l][1], generator=g, device=dev, dtype=dtype)
+              for _, l, _ in blocks]
+
+    def step(inject_on):
+        for blk, _, injected in blocks:
+            blk.attn1.t = 5 if inject_on else 7
+        # the reference runs its UNet passes under autocast (run_tokenflow_pnp.py:220)
+        with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+            tfu.register_pivotal(holder, True)
+            for (blk, _, _), x in zip(blocks, xs_piv):
+                blk(x)
+            tfu.register_pivotal(holder, False)
+            for c in range(K):
+                tfu.register_batch_idx(holder, c)
+                for (blk, _, _), x in zip(blocks, xs_chk):
+                    blk(x)
+
+    for i in range(2):
+        step(i % 2 == 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i % 2 == 0)
+    t_cpu = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    print(f"hooks path, {cfg.name}: {t / steps * 1e3:.2f} ms/step ({cfg.frames * steps / t:.0f} frames/s); "
+          f"host-side issue time {t_cpu / steps * 1e3:.2f} ms/step")
+
+
+if __name__ == "__main__":
+    main()
