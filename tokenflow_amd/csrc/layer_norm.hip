@@ -5,7 +5,7 @@
 // Here: one pass, 16-bit (or fp32) in, fp32 statistics, one rounding to the output type, and -- for the
 // pivots of the NN search -- 1/||y||_2 of the ROUNDED output row as a side product (what
 // tf_pivot_inv_norm computes from the stored pivots, util.py:67), so the pivots are never re-read.
-// One wave per row, the row lives in registers (D <= 2048); HBM-bound.
+// 16/32/64 lanes per row by D, the row lives in registers (D <= 2048); HBM-bound.
 #include "tf_common.h"
 
 namespace {
@@ -68,52 +68,60 @@ __device__ __forceinline__ void ln_load_w(const void* w, int w_dtype, int col, f
     }
 }
 
-__device__ __forceinline__ float wave_sum(float x) {
+// sum over the LPR lanes that share a row (LPR = 16, 32 or 64 consecutive lanes)
+template <int LPR>
+__device__ __forceinline__ float row_sum(float x) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    for (int o = LPR / 2; o > 0; o >>= 1) x += __shfl_xor(x, o);
     return x;
 }
 
-constexpr int LN_MAXP = 4;   // 16-B pieces per lane: D <= 64 * 8 * 4 = 2048
+constexpr int LN_MAXP = 4;   // 16-B pieces per lane
 
-template <typename TIn, typename TOut>
+// LPR lanes per row, 64/LPR rows per wave: a row of D = 320 is 40 pieces -- with a whole wave per row a third of
+// the lanes idle and every row pays three full-wave reductions; 16 lanes per row keep all lanes busy on 4 rows.
+// D <= LPR * 8 * LN_MAXP.
+template <typename TIn, typename TOut, int LPR>
 __global__ __launch_bounds__(256) void layer_norm_kernel(const TIn* __restrict__ x, const void* __restrict__ gamma,
                                                          const void* __restrict__ beta, TOut* __restrict__ out,
                                                          float* __restrict__ inv_norm, int64_t rows, int D, float eps,
                                                          int w_dtype) {
+    constexpr int RPW = 64 / LPR;   // rows per wave
     const int lane = threadIdx.x & 63;
+    const int lr = lane % LPR;      // lane within its row
     const int pieces = D >> 3;
     const float inv_d = 1.0f / (float)D;
-    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    for (int64_t r = row0; r < rows; r += (int64_t)gridDim.x * 4 * RPW) {
         const TIn* xr = x + r * D;
         float v[LN_MAXP][8];
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < LN_MAXP; ++j) {
-            const int p = lane + 64 * j;
+            const int p = lr + LPR * j;
             if (p < pieces) {
                 ln_load8(xr + p * 8, v[j]);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) s += v[j][i];
             }
         }
-        const float mean = wave_sum(s) * inv_d;
+        const float mean = row_sum<LPR>(s) * inv_d;
         float q = 0.f;
 #pragma unroll
         for (int j = 0; j < LN_MAXP; ++j)
-            if (lane + 64 * j < pieces) {
+            if (lr + LPR * j < pieces) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float c = v[j][i] - mean;
                     q = fmaf(c, c, q);
                 }
             }
-        const float rstd = 1.0f / __builtin_sqrtf(wave_sum(q) * inv_d + eps);   // biased variance, as torch
+        const float rstd = 1.0f / __builtin_sqrtf(row_sum<LPR>(q) * inv_d + eps);   // biased variance, as torch
         float ss = 0.f;
         TOut* orow = out + r * D;
 #pragma unroll
         for (int j = 0; j < LN_MAXP; ++j) {
-            const int p = lane + 64 * j;
+            const int p = lr + LPR * j;
             if (p < pieces) {
                 float g[8], b[8], y[8];
                 ln_load_w(gamma, w_dtype, p * 8, 1.f, g);
@@ -124,20 +132,29 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const TIn* __restrict__
             }
         }
         if (inv_norm != nullptr) {
-            ss = wave_sum(ss);
-            if (lane == 0) inv_norm[r] = 1.0f / __builtin_sqrtf(ss);
+            ss = row_sum<LPR>(ss);
+            if (lr == 0) inv_norm[r] = 1.0f / __builtin_sqrtf(ss);
         }
     }
+}
+
+template <typename TIn, typename TOut, int LPR>
+void launch_ln_lpr(const void* x, const void* gamma, const void* beta, void* out, float* inv_norm, int64_t rows,
+                   int D, float eps, int w_dtype, hipStream_t st) {
+    constexpr int rows_per_wg = 4 * (64 / LPR);
+    int64_t blocks = (rows + rows_per_wg - 1) / rows_per_wg;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL((layer_norm_kernel<TIn, TOut, LPR>), dim3((unsigned)blocks), dim3(256), 0, st,
+                       reinterpret_cast<const TIn*>(x), gamma, beta, reinterpret_cast<TOut*>(out), inv_norm, rows, D,
+                       eps, w_dtype);
 }
 
 template <typename TIn, typename TOut>
 void launch_ln(const void* x, const void* gamma, const void* beta, void* out, float* inv_norm, int64_t rows, int D,
                float eps, int w_dtype, hipStream_t st) {
-    int64_t blocks = (rows + 3) / 4;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL((layer_norm_kernel<TIn, TOut>), dim3((unsigned)blocks), dim3(256), 0, st,
-                       reinterpret_cast<const TIn*>(x), gamma, beta, reinterpret_cast<TOut*>(out), inv_norm, rows, D,
-                       eps, w_dtype);
+    if (D <= 16 * 8 * LN_MAXP) launch_ln_lpr<TIn, TOut, 16>(x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st);
+    else if (D <= 32 * 8 * LN_MAXP) launch_ln_lpr<TIn, TOut, 32>(x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st);
+    else launch_ln_lpr<TIn, TOut, 64>(x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st);
 }
 
 template <typename TIn>
