@@ -174,33 +174,33 @@ class FrameShard:
     def exchange_halo(self, pivots_local: torch.Tensor, inv_local: torch.Tensor, kf_out_local: torch.Tensor):
         """pivots_local [Kl,S,D], inv_local [Kl,S], kf_out_local [3*Kl,S,D] (this rank's keyframes).
         Returns the same three with ONE extra leading keyframe slot = the previous rank's last
-        keyframe (unused zeros on rank 0: global chunk 0 matches a single keyframe, 331-333)."""
+        keyframe (unset and unread on rank 0: global chunk 0 matches a single keyframe, 331-333)."""
         Kl = self.Kl
         if self.world == 1:
             return pivots_local, inv_local, kf_out_local      # no halo slot: ids are [c, c-1] directly
         _, S, D = pivots_local.shape
-        piv = torch.zeros(Kl + 1, S, D, dtype=pivots_local.dtype, device=pivots_local.device)
-        inv = torch.zeros(Kl + 1, S, dtype=inv_local.dtype, device=inv_local.device)
-        kfo = torch.zeros(3, Kl + 1, S, D, dtype=kf_out_local.dtype, device=kf_out_local.device)
+        # slot 0 = the left neighbour's last keyframe; on rank 0 it stays unset and is never read
+        # (global chunk 0 matches keyframe 0 alone)
+        piv = torch.empty(Kl + 1, S, D, dtype=pivots_local.dtype, device=pivots_local.device)
+        inv = torch.empty(Kl + 1, S, dtype=inv_local.dtype, device=inv_local.device)
+        kfo = torch.empty(3, Kl + 1, S, D, dtype=kf_out_local.dtype, device=kf_out_local.device)
+        kf3 = kf_out_local.view(3, Kl, S, D)
         piv[1:].copy_(pivots_local)
         inv[1:].copy_(inv_local)
-        kfo[:, 1:].copy_(kf_out_local.view(3, Kl, S, D))
-        if self.world > 1:
-            sends, recvs, opsl = [], [], []
-            if self.rank + 1 < self.world:
-                sends = [pivots_local[-1].contiguous(), inv_local[-1].contiguous(),
-                         kf_out_local.view(3, Kl, S, D)[:, -1].contiguous()]
-                opsl += [dist.P2POp(dist.isend, t, self._peer(self.rank + 1), self.group) for t in sends]
-            if self.rank > 0:
-                recvs = [torch.empty_like(piv[0]), torch.empty_like(inv[0]),
-                         torch.empty(3, S, D, dtype=kfo.dtype, device=kfo.device)]
-                opsl += [dist.P2POp(dist.irecv, t, self._peer(self.rank - 1), self.group) for t in recvs]
-            for req in (dist.batch_isend_irecv(opsl) if opsl else []):
-                req.wait()
-            if recvs:
-                piv[0].copy_(recvs[0])
-                inv[0].copy_(recvs[1])
-                kfo[:, 0].copy_(recvs[2])
+        kfo[:, 1:].copy_(kf3)
+        # one grouped point-to-point exchange, no staging copies: every message is a contiguous view
+        # (the attention output travels as one message per branch)
+        opsl = []
+        if self.rank + 1 < self.world:
+            peer = self._peer(self.rank + 1)
+            opsl += [dist.P2POp(dist.isend, t, peer, self.group)
+                     for t in (pivots_local[-1], inv_local[-1], kf3[0, -1], kf3[1, -1], kf3[2, -1])]
+        if self.rank > 0:
+            peer = self._peer(self.rank - 1)
+            opsl += [dist.P2POp(dist.irecv, t, peer, self.group)
+                     for t in (piv[0], inv[0], kfo[0, 0], kfo[1, 0], kfo[2, 0])]
+        for req in (dist.batch_isend_irecv(opsl) if opsl else []):
+            req.wait()
         return piv, inv, kfo.view(3 * (Kl + 1), S, D)
 
     def _peer(self, group_rank: int) -> int:
