@@ -191,9 +191,11 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     //   key norm bound comes with the vt_pack_kernel pre-pass), so while  |q'| |k|max - shift <= FOLD_T  no
     //   score of any tile can exceed the threshold and the max3 chain + permlane (16 of ~66 VALU per tile)
     //   is skipped; a query whose bound is loose falls back to the per-tile maximum.  exp2 of FOLD_T must
-    //   stay far inside the input type's range with room for the row sum: 2^60 for bf16, 2^8 for f16.
+    //   stay inside the input type's range (the row sum is accumulated in fp32): 2^60 for bf16, 2^14 for f16
+    //   (f16 tops out at 65504; on N(0,1) data the f16 bound is usually too loose to skip anything, and a
+    //   per-tile bound from the block's own max |k| measured slower than the fallback it avoids).
     //   Measured (MI355X, cfg2 level 0): -6.5 % kernel time for +7..15 us in the pre-pass.
-    constexpr float FOLD_T = std::is_same<E, _Float16>::value ? 8.0f : 60.0f;
+    constexpr float FOLD_T = std::is_same<E, _Float16>::value ? 14.0f : 60.0f;
     constexpr bool BOUND = FOLD;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

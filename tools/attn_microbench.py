@@ -26,16 +26,18 @@ def time_it(fn, reps=8, warm=2):
 
 def main():
     shapes = [(8, 4096, 8, 40), (8, 1024, 8, 80), (8, 256, 8, 160), (10, 9216, 5, 64)]
-    if len(sys.argv) > 1:
-        shapes = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
+    args = [a for a in sys.argv[1:] if a not in ("f16", "bf16")]
+    dt = torch.float16 if "f16" in sys.argv[1:] else torch.bfloat16
+    if args:
+        shapes = [tuple(int(x) for x in a.split(",")) for a in args]
     g = torch.Generator(device="cuda").manual_seed(0)
     for K, S, h, d in shapes:
         D = h * d
-        q, k, v = (torch.randn(3 * K, S, D, generator=g, device="cuda").bfloat16() for _ in range(3))
+        q, k, v = (torch.randn(3 * K, S, D, generator=g, device="cuda").to(dt) for _ in range(3))
         fl = workload.attn_flops(K, S, D)
         for inj in (False, True):
             avg, mn = time_it(lambda: ops.ext_attn(q, k, v, h, d ** -0.5, inj), reps=6 if S > 4096 else 10)
-            print(f"ext_attn K={K} S={S} h={h} d={d} inject={int(inj)}: avg {avg:.3f} ms  min {mn:.3f} ms  "
+            print(f"ext_attn {str(dt)[6:]} K={K} S={S} h={h} d={d} inject={int(inj)}: avg {avg:.3f} ms  min {mn:.3f} ms  "
                   f"{fl / avg / 1e9:.0f} TF/s", flush=True)
 
 
