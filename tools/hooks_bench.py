@@ -5,7 +5,7 @@ part of the path (q/k/v/out projections, cross-attention, feed-forward) replaced
 is timed is the hook layer itself: norm1, dtype casts, Python, and the HIP ops.  Compare with bench.py, which
 calls the ops directly on pre-made tensors.
 
-    python tools/hooks_bench.py [cfg2] [steps]
+    python tools/hooks_bench.py [cfg2] [steps] [--proj]     (--proj: keep attn1's q/k/v/out Linear layers)
 """
 import os
 import sys
@@ -32,8 +32,9 @@ def build(cfg, dev, dtype):
     for i, (lvl, injected) in enumerate(workload.BLOCKS):
         S, D, h = cfg.levels[lvl]
         blk = fd.BasicTransformerBlock(D, h, cross_dim=32)
-        blk.attn1.to_q, blk.attn1.to_k, blk.attn1.to_v = _Id(), _Id(), _Id()
-        blk.attn1.to_out = torch.nn.ModuleList([_Id(), _Id()])
+        if not PROJ:
+            blk.attn1.to_q, blk.attn1.to_k, blk.attn1.to_v = _Id(), _Id(), _Id()
+            blk.attn1.to_out = torch.nn.ModuleList([_Id(), _Id()])
         blk.attn2 = None
         blk.ff = _Id()
         setattr(holder.unet, f"blk{i}", blk)
@@ -42,9 +43,13 @@ def build(cfg, dev, dtype):
     return holder, blocks
 
 
+PROJ = "--proj" in sys.argv      # keep the real q/k/v/out Linear layers of attn1 (default: identities)
+
+
 def main():
-    cfg = workload.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    cfg = workload.CONFIGS[argv[0] if len(argv) > 0 else "cfg2"]
+    steps = int(argv[1]) if len(argv) > 1 else 6
     dev, dtype = torch.device("cuda"), torch.bfloat16
     holder, blocks = build(cfg, dev, dtype)
     from tokenflow_amd import hooks
