@@ -76,7 +76,8 @@ const char* tf_last_error(void);
  *   to the input dtype once, relative error <= 2^-9 per element; +12 % speed); this flag keeps the
  *   reference's fp32 scaling of the scores.  No effect at other head dims.
  *   scale = attn.scale (Dh^-0.5).  Dh in {40, 64, 80, 160}; dtype bf16 or f16;
- *   S, ld multiples of 8.  fp32 softmax / accumulation, online softmax over
+ *   any S >= 1 (latent grids of odd resolutions: 9x5 = 45 tokens at the mid block of 576x320);
+ *   ld a multiple of 8.  fp32 softmax / accumulation, online softmax over
  *   64-key tiles, P rounded to the input dtype before P.V (as the reference's
  *   autocast path does).
  *

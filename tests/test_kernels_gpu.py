@@ -122,7 +122,9 @@ def test_ext_attn_vs_oracle_and_golden(name, dtype, golden_attn):
                                      # counts, ragged last tile, several keyframes
                                      (1, 512, 1, 64), (2, 576, 2, 64), (2, 520, 1, 64), (3, 640, 2, 64),
                                      # S >= 256 at Dh = 40 / 80: 8-wave geometry and the dual (shared-softmax) form
-                                     (2, 328, 2, 40), (2, 264, 1, 80)])
+                                     (2, 328, 2, 40), (2, 264, 1, 80),
+                                     # token counts that are not multiples of 8 (odd latent grids: 9x5, 18x10+1 ...)
+                                     (2, 45, 2, 160), (3, 181, 2, 80), (2, 723, 1, 40), (2, 515, 1, 64), (1, 1, 1, 40)])
 @pytest.mark.parametrize("inject", [False, True])
 def test_ext_attn_shapes(K, S, h, d, inject):
     """Ragged S (not a multiple of 64 / 128), single keyframe, many heads, K > 12."""

@@ -1044,8 +1044,8 @@ extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void
     TF_ARG(dtype == TF_BF16 || dtype == TF_F16, TF_ERR_DTYPE, "tf_ext_attn_fwd: dtype %d (bf16/f16 only)", dtype);
     TF_ARG(Dh == 40 || Dh == 64 || Dh == 80 || Dh == 160, TF_ERR_SHAPE,
            "tf_ext_attn_fwd: head dim %d not in {40,64,80,160}", Dh);
-    TF_ARG(K > 0 && S > 0 && H > 0 && S % 8 == 0 && ld >= (int64_t)H * Dh && ld % 8 == 0, TF_ERR_SHAPE,
-           "tf_ext_attn_fwd: K=%d S=%d H=%d ld=%lld (S, ld multiples of 8; ld >= H*Dh)", K, S, H, (long long)ld);
+    TF_ARG(K > 0 && S > 0 && H > 0 && ld >= (int64_t)H * Dh && ld % 8 == 0, TF_ERR_SHAPE,
+           "tf_ext_attn_fwd: K=%d S=%d H=%d ld=%lld (ld a multiple of 8, >= H*Dh)", K, S, H, (long long)ld);
     TF_ARG(Kq > 0 && q_frame0 >= 0 && q_frame0 + Kq <= K, TF_ERR_SHAPE,
            "tf_ext_attn_fwd: query frames [%d, %d) outside the %d-frame bank", q_frame0, q_frame0 + Kq, K);
     TF_ARG(tf_aligned16(q) && tf_aligned16(k) && tf_aligned16(v) && tf_aligned16(out) && tf_aligned16(ws),
