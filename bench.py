@@ -200,9 +200,11 @@ def main():
     blocks = [Block(cfg, lvl, inj, shard, gen, dev) for lvl, inj in workload.BLOCKS]
     w = blend_w(cfg.chunk, dev)
     exchange = None if args.pivotal_exchange == "auto" else args.pivotal_exchange
-    heads_ok = all(l[2] % world == 0 for l in cfg.levels)
-    exch_name = {"heads": "frames<->heads all-to-all", "bank": "K/V bank all-gather"}[
-        exchange or ("heads" if heads_ok else "bank")]
+    n_heads_ok = sum(1 for l in cfg.levels if l[2] % world == 0)
+    names = {"heads": "frames<->heads all-to-all", "bank": "K/V bank all-gather"}
+    exch_name = (names[exchange] if exchange else names["heads"] if n_heads_ok == len(cfg.levels)
+                 else names["bank"] if n_heads_ok == 0
+                 else "frames<->heads all-to-all on the levels whose heads divide over the ranks, K/V bank all-gather on the others")
 
     def barrier():
         if world > 1:
