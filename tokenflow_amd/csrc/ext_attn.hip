@@ -167,7 +167,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     constexpr int NT = 64 * NW;
     constexpr int NB = MODE == MODE_DUAL ? 2 : 1;   // V banks handled by this workgroup
     constexpr int NPK = C::npk(NT), NPV = C::npv(NT);
-    constexpr int BUF_ELEMS = C::K_ELEMS + NB * C::V_ELEMS;
+    // PACK (dual-V at Dh = 40): the two banks' V^T rows share ONE LDS image of 3 M-tiles -- rows 0-39 uncond,
+    // 40-79 cond, row 80 = 1.0 (the common denominator row), 81-95 zero -- instead of two images of 2 M-tiles
+    // with 24 idle rows each: 12 instead of 16 P.V MFMAs per 64-key tile (18 instead of 22 with QK^T).
+    constexpr bool PACK = MODE == MODE_DUAL && DH == 40;
+    constexpr int VIMG_ROWS = PACK ? 96 : NB * C::VROWS;       // V^T rows of one LDS buffer
+    constexpr int VB_ROWS = PACK ? DH : C::VROWS;              // row offset between the banks inside it
+    constexpr int BUF_ELEMS = C::K_ELEMS + VIMG_ROWS * C::VROW;
     // When the head dim is not a multiple of 32 the last PV M-tile has unused rows: row DH of the
     // V^T image is set to 1.0, so that accumulator row collects sum_k P[k] -- the softmax
     // denominator comes out of the MFMA for free, summed over the SAME rounded P as the numerator.
@@ -200,7 +206,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     auto sK = [&](int buf) { return reinterpret_cast<E*>(smem) + buf * BUF_ELEMS; };
-    auto sV = [&](int buf, int vb) { return reinterpret_cast<E*>(smem) + buf * BUF_ELEMS + C::K_ELEMS + vb * C::V_ELEMS; };
+    auto sV = [&](int buf, int vb) {
+        return reinterpret_cast<E*>(smem) + buf * BUF_ELEMS + C::K_ELEMS + vb * VB_ROWS * C::VROW;
+    };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -251,7 +259,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
             sK(bufi)[r * C::KROW + DH + cidx] = (E)((FOLD && cidx == 0) ? 1.f : 0.f);
         }
     }
-    if constexpr (C::VROWS > DH) {
+    if constexpr (PACK) {
+        for (int id = tid; id < 2 * (VIMG_ROWS - NB * DH) * KT; id += NT) {
+            const int bufi = id / ((VIMG_ROWS - NB * DH) * KT);
+            const int r = (id / KT) % (VIMG_ROWS - NB * DH), cidx = id % KT;
+            sV(bufi, 0)[(NB * DH + r) * C::VROW + cidx] = (E)(r == 0 ? 1.f : 0.f);
+        }
+    } else if constexpr (C::VROWS > DH) {
         for (int id = tid; id < 2 * NB * (C::VROWS - DH) * KT; id += NT) {
             const int bv = id / ((C::VROWS - DH) * KT);
             const int r = (id / KT) % (C::VROWS - DH), cidx = id % KT;
@@ -494,16 +508,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
                     if constexpr (!ONES) l_run[qi] += lsum;
                 }
                 // ---- O^T += V^T . P  (once per V bank)
-                if constexpr (MODE == MODE_DUAL && DH == 40) {   // measured: the chain order is 1 % faster here
+                if constexpr (PACK) {   // 3 M-tiles over the packed image: accumulators o[0][.][0], o[0][.][1], o[1][.][0]
 #pragma unroll
-                    for (int vb = 0; vb < NB; ++vb)
+                    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                        for (int mt = 0; mt < C::MT; ++mt) {
-                            const E* vrow = sV(buf, vb) + (mt * 32 + l31) * C::VROW + sub * 64 + 8 * hi;
-#pragma unroll
-                            for (int ks = 0; ks < 4; ++ks)
-                                o[vb][qi][mt] =
-                                    T::mfma32(__builtin_bit_cast(vec8, ld16(vrow + 16 * ks)), pf[ks], o[vb][qi][mt]);
+                        for (int g = 0; g < 3; ++g) {
+                            const E* vrow = sV(buf, 0) + (g * 32 + l31) * C::VROW + sub * 64 + 8 * hi;
+                            o[g >> 1][qi][g & 1] = T::mfma32(__builtin_bit_cast(vec8, ld16(vrow + 16 * ks)), pf[ks],
+                                                             o[g >> 1][qi][g & 1]);
                         }
                 } else {
 #pragma unroll
@@ -530,12 +542,30 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
 #pragma unroll
     for (int qi = 0; qi < QT; ++qi) {
         float l_tot;
-        if constexpr (ONES)
+        if constexpr (PACK)
+            l_tot = __shfl(o[1][qi][0][8], l31);   // image row 80 = row 16 of the third M-tile: register 8, lane half 0
+        else if constexpr (ONES)
             l_tot = __shfl(o[0][qi][C::MT - 1][ONES_R], l31);  // row DH lives in lane half 0 of the last M-tile
         else
             l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32);
         const float inv_l = 1.0f / l_tot;
-        if (q_ok[qi]) {
+        if (PACK && q_ok[qi]) {
+            E* op0 = reinterpret_cast<E*>(p.out) + (((int64_t)b * Kq + f) * S + q_row[qi]) * ((int64_t)H * DH) + h * DH;
+            const int64_t branch = (int64_t)Kq * S * H * DH;
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int R = g * 32 + 8 * rg + 4 * hi;    // image row of this group of 4 (never straddles a bank)
+                    if (R < NB * DH) {
+                        const int vb = R >= DH ? 1 : 0;
+                        vec4 w;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) w[i] = (E)(o[g >> 1][qi][g & 1][rg * 4 + i] * inv_l);
+                        *reinterpret_cast<u32x2*>(op0 + vb * branch + (R - vb * DH)) = __builtin_bit_cast(u32x2, w);
+                    }
+                }
+        } else if (q_ok[qi]) {
 #pragma unroll
             for (int vb = 0; vb < NB; ++vb) {
                 E* op = reinterpret_cast<E*>(p.out) +
@@ -962,7 +992,8 @@ int launch_pp(AttnParams p, hipStream_t st) {
 template <typename T, int DH, int QT, int NW, int MODE, int MINW, bool FQ = true, int KT = 64>
 int launch_one(AttnParams p, hipStream_t st) {
     typedef AttnCfg<DH, KT> C;
-    constexpr size_t lds = C::lds_bytes(MODE == MODE_DUAL ? 2 : 1);
+    constexpr size_t lds = (MODE == MODE_DUAL && DH == 40) ? 2 * (size_t)(C::K_ELEMS + 96 * C::VROW) * 2   // PACK
+                                                            : C::lds_bytes(MODE == MODE_DUAL ? 2 : 1);
     auto kern = ext_attn_kernel<T, DH, QT, NW, MODE, MINW, KT, FQ>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
