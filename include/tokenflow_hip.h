@@ -42,6 +42,7 @@ extern "C" {
 #define TF_ATTN_EXACT_SCALE 2  /* scale the scores in fp32 (no folding of scale*log2e into q) */
 #define TF_ATTN_BANK_ONLY 4    /* compute only the uncond and cond branches (those that read the K-frame bank) */
 #define TF_ATTN_SOURCE_ONLY 8  /* compute only the source branch (own-frame keys) */
+#define TF_ATTN_NO_SPLIT 16    /* never split a bank problem over workgroups (one pass, bit-stable across grid sizes) */
 
 /* argument errors */
 #define TF_ERR_NULL (-1)
@@ -81,7 +82,15 @@ const char* tf_last_error(void);
  *   64-key tiles, P rounded to the input dtype before P.V (as the reference's
  *   autocast path does).
  *
- *   ws: scratch for the transposed V bank; size from tf_ext_attn_workspace_bytes.
+ *   inject & TF_ATTN_BANK_ONLY / TF_ATTN_SOURCE_ONLY: compute only the uncond + cond branches / only the
+ *   source branch (the head-sharded multi-GPU path runs them on different tensors); slabs of q, k, v, out
+ *   that the selected part does not need are never touched.
+ *   Small grids (a sharded rank, the coarse levels) split every bank problem into runs of bank frames over
+ *   extra workgroups and merge the partial results (fp32) in a second launch; TF_ATTN_NO_SPLIT keeps the
+ *   one-pass form, whose arithmetic per (query, head) does not depend on the grid.
+ *
+ *   ws: scratch for the transposed V bank (+ key norms, + split-form partials); size from
+ *   tf_ext_attn_workspace_bytes.
  * ------------------------------------------------------------------------ */
 size_t tf_ext_attn_workspace_bytes(int K, int S, int H, int Dh, int dtype);
 

@@ -126,15 +126,47 @@ def test_ext_attn_vs_oracle_and_golden(name, dtype, golden_attn):
                                      # token counts that are not multiples of 8 (odd latent grids: 9x5, 18x10+1 ...)
                                      (2, 45, 2, 160), (3, 181, 2, 80), (2, 723, 1, 40), (2, 515, 1, 64), (1, 1, 1, 40)])
 @pytest.mark.parametrize("inject", [False, True])
-def test_ext_attn_shapes(K, S, h, d, inject):
-    """Ragged S (not a multiple of 64 / 128), single keyframe, many heads, K > 12."""
+@pytest.mark.parametrize("no_split", [False, True])
+def test_ext_attn_shapes(K, S, h, d, inject, no_split, monkeypatch):
+    """Ragged S (not a multiple of 64 / 128), single keyframe, many heads, K > 12.  These grids are small, so by
+    default the bank problems run in the split form (runs of bank frames + merge); no_split forces the one-pass
+    form on the same inputs."""
     ops = _ops()
+    monkeypatch.setattr(ops, "NO_SPLIT", no_split)
     g = torch.Generator().manual_seed(K * 1000 + S + d)
     D = h * d
     q, k, v = (orc.bf16_round(torch.randn(3 * K, S, D, generator=g)) for _ in range(3))
     refs = attn_ref(q, k, v, h, d ** -0.5, inject)
     out = ops.ext_attn(q.bfloat16().cuda(), k.bfloat16().cuda(), v.bfloat16().cuda(), h, d ** -0.5, inject)
-    assert_attn_close(out, refs, f"K{K} S{S} h{h} d{d} inj{inject}", folded=d == 40)
+    assert_attn_close(out, refs, f"K{K} S{S} h{h} d{d} inj{inject} no_split{no_split}", folded=d == 40)
+
+
+@pytest.mark.parametrize("K,S,h,d", [(8, 256, 1, 40), (8, 1024, 1, 80), (8, 576, 2, 64), (5, 328, 1, 40), (7, 200, 2, 80),
+                                     (8, 64, 1, 40)])
+@pytest.mark.parametrize("inject", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_ext_attn_split_form(K, S, h, d, inject, dtype, monkeypatch):
+    """Shapes of a head-sharded rank (one head group, all keyframes): the bank is split into runs of frames over
+    extra workgroups and merged (attn_merge_kernel).  Against the oracle with the usual bound, and against the
+    one-pass form of the same call within the output rounding."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(K * 77 + S + d)
+    D = h * d
+    rnd = orc.bf16_round if dtype == torch.bfloat16 else (lambda x: x.half().float())
+    q, k, v = (rnd(torch.randn(3 * K, S, D, generator=g)) for _ in range(3))
+    refs = attn_ref(q, k, v, h, d ** -0.5, inject)
+    dq, dk, dv = (t.to(dtype).cuda() for t in (q, k, v))
+    monkeypatch.setattr(ops, "NO_SPLIT", False)
+    out = ops.ext_attn(dq, dk, dv, h, d ** -0.5, inject)
+    assert_attn_close(out, refs, f"split K{K} S{S} h{h} d{d} inj{inject}", dtype=dtype, folded=d == 40)
+    monkeypatch.setattr(ops, "NO_SPLIT", True)
+    one = ops.ext_attn(dq, dk, dv, h, d ** -0.5, inject)
+    assert_attn_close(one, refs, f"one-pass K{K} S{S} h{h} d{d} inj{inject}", dtype=dtype, folded=d == 40)
+    diff = (out.float() - one.float()).abs().cpu()     # both within the bound of the oracle; typically 0 or 1 ulp apart
+    ref, ref_abs, sigma = refs
+    assert bool((diff <= 2 * attn_bound(ref, ref_abs, dtype, sigma if d == 40 else None)).all())
+    assert float(diff.mean()) < 2e-4
+    assert torch.equal(out.view(3, -1)[0], one.view(3, -1)[0])      # the source branch is never split
 
 
 def test_ext_attn_strided_qkv():

@@ -18,12 +18,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, K, inject, mode, ret):
+def _worker(rank, world, port, K, inject, mode, no_split, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from tokenflow_amd import ops, sharded
         torch.cuda.set_device(0)
+        ops.NO_SPLIT = no_split
 
         n, S, h, d = 2, 320, 2, 40
         D = h * d
@@ -46,10 +47,18 @@ def _worker(rank, world, port, K, inject, mode, ret):
         Kl, f0 = sh.Kl, sh.kf0
         loc = lambda t: t.view(3, K, S, D)[:, f0:f0 + Kl].reshape(3 * Kl, S, D)
         out = sh.pivotal_attention(loc(q), loc(k), loc(v), h, d ** -0.5, inject, mode=mode)
-        ok = torch.equal(out, loc(full))
+        if no_split:     # same arithmetic per (query, head) whoever computes it
+            ok = torch.equal(out, loc(full))
+        else:            # small grids split the bank and merge: fp32 sums re-associated, bf16 outputs within a rounding
+            a, r = out.float(), loc(full).float()
+            ok = bool(((a - r).abs() <= 2.0 ** -7 * r.abs() + 1e-3).all())
         pe, ie, ke = sh.exchange_halo(piv[f0:f0 + Kl], inv[f0:f0 + Kl], out)
         for j in range(Kl):
-            ok = ok and torch.equal(sh.propagate(j, tgt[f0 + j], res[f0 + j], pe, ie, ke, w, n), ref[f0 + j])
+            y = sh.propagate(j, tgt[f0 + j], res[f0 + j], pe, ie, ke, w, n)
+            if no_split:
+                ok = ok and torch.equal(y, ref[f0 + j])
+            else:        # same indices, gathered rows within the attention tolerance above
+                ok = ok and bool(((y.float() - ref[f0 + j].float()).abs() <= 2.0 ** -6 * ref[f0 + j].float().abs() + 2e-3).all())
         torch.cuda.synchronize()
         ret[rank] = bool(ok)
     finally:
@@ -59,10 +68,12 @@ def _worker(rank, world, port, K, inject, mode, ret):
 @pytest.mark.parametrize("K,mode,inject", [(4, "heads", False), (4, "heads", True), (4, "bank", False),
                                            (4, "bank", True), (5, "heads", True), (5, "heads", False),
                                            (5, "bank", False)])
-def test_sharded_real_kernels_two_ranks(K, mode, inject):
-    """K = 5: uneven runs (3 + 2 keyframes)."""
+@pytest.mark.parametrize("no_split", [True, False])
+def test_sharded_real_kernels_two_ranks(K, mode, inject, no_split):
+    """K = 5: uneven runs (3 + 2 keyframes).  no_split: one-pass attention everywhere -> bit-identical to the
+    single-GPU run; default: small grids split the bank over workgroups -> equal within the output rounding."""
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, K, inject, mode, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, K, inject, mode, no_split, ret), nprocs=2, join=True)
     assert dict(ret) == {0: True, 1: True}

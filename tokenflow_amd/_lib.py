@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TOKENFLOW_HIP_LIB") or os.path.join(_HERE, "libtokenflow_hip.so")
 
 TF_BF16, TF_F16, TF_F32 = 0, 1, 2
-TF_ATTN_INJECT, TF_ATTN_EXACT_SCALE, TF_ATTN_BANK_ONLY, TF_ATTN_SOURCE_ONLY = 1, 2, 4, 8
+TF_ATTN_INJECT, TF_ATTN_EXACT_SCALE, TF_ATTN_BANK_ONLY, TF_ATTN_SOURCE_ONLY, TF_ATTN_NO_SPLIT = 1, 2, 4, 8, 16
 ABI_VERSION = 1
 
 _c = ctypes

@@ -66,7 +66,9 @@ struct AttnParams {
     const float* knorm2;  // [3][H][K*Spad/64] max |k|^2 per 64-key block, FOLD kernels only (from vt_pack_kernel)
     void* out;
     int K, Kq, q_frame0, S, H, Spad, nQT, inject, exact_scale;
-    int part;  // 0 = all three branches, TF_ATTN_BANK_ONLY, TF_ATTN_SOURCE_ONLY  // K bank frames; queries = frames q_frame0 .. +Kq
+    int part;  // 0 = all three branches, TF_ATTN_BANK_ONLY, TF_ATTN_SOURCE_ONLY
+    int nseg;          // > 1: every bank problem is split into nseg runs of bank frames (small grids, see split_plan)
+    float* partials;   // [2 banks][Kq][H][S][nseg][Dh + 8] fp32: unnormalised O, l, log2-domain shift  // K bank frames; queries = frames q_frame0 .. +Kq
     int64_t ld;
     float c;  // scale * log2(e)
 };
@@ -221,23 +223,32 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     const int h = blockIdx.x % H;
     int u = blockIdx.x / H;
     int b, f, qt;  // f = query frame, local index in [0, Kq)
+    int seg = 0;   // run of bank frames this workgroup covers (split form: the bank problems come nseg times)
+    const int nseg = MODE == MODE_SOURCE ? 1 : p.nseg;
     if constexpr (MODE == MODE_ALL) {   // bank problems (uncond, cond) first, then the short source ones
-        const int nbank = 2 * Kq * p.nQT;
+        const int nbank = 2 * Kq * p.nQT * nseg;
         if (u < nbank) {
+            seg = u % nseg;
+            u /= nseg;
             b = 1 + u / (Kq * p.nQT);
             u -= (b - 1) * Kq * p.nQT;
         } else {
             u -= nbank;
             b = 0;
         }
+    } else if constexpr (MODE == MODE_DUAL) {
+        b = 1;
+        seg = u % nseg;
+        u /= nseg;
     } else {
-        b = MODE == MODE_DUAL ? 1 : 0;
+        b = 0;
     }
     f = u / p.nQT;
     qt = u - f * p.nQT;
     const int bq = (p.inject && b > 0) ? 0 : b;  // branch whose q and k are used (tokenflow_utils.py:124-130)
-    const int f_lo = b == 0 ? p.q_frame0 + f : 0;
-    const int n_fr = b == 0 ? 1 : K;
+    const bool split = nseg > 1 && b > 0;
+    const int f_lo = b == 0 ? p.q_frame0 + f : (seg * K) / nseg;
+    const int n_fr = b == 0 ? 1 : ((seg + 1) * K) / nseg - f_lo;
     const int tpf = (S + KT - 1) / KT;  // staged tiles per frame
     const int ntiles = n_fr * tpf;
     const bool ragged = (S % KT) != 0;
@@ -549,7 +560,55 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
         else
             l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32);
         const float inv_l = 1.0f / l_tot;
-        if (PACK && q_ok[qi]) {
+        if (split) {
+            // split form: this workgroup saw only a run of the bank's frames -- leave the unnormalised O, the
+            // denominator and the shift (log2 domain) for attn_merge_kernel
+            if (q_ok[qi]) {
+                constexpr int PS = DH + 8;
+                const float lshift = FOLD ? m_run[qi] : m_run[qi] * c;
+                auto row_ptr = [&](int vb) {
+                    const int64_t R = (((int64_t)(b - 1 + vb) * Kq + f) * H + h) * S + q_row[qi];
+                    return p.partials + (R * nseg + seg) * PS;
+                };
+                if constexpr (PACK) {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const int R = g * 32 + 8 * rg + 4 * hi;
+                            if (R < NB * DH) {
+                                const int vb = R >= DH ? 1 : 0;
+                                f32x4 w;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) w[i] = o[g >> 1][qi][g & 1][rg * 4 + i];
+                                *reinterpret_cast<f32x4*>(row_ptr(vb) + (R - vb * DH)) = w;
+                            }
+                        }
+                } else {
+#pragma unroll
+                    for (int vb = 0; vb < NB; ++vb)
+#pragma unroll
+                        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                            for (int rg = 0; rg < 4; ++rg) {
+                                const int d0 = mt * 32 + 8 * rg + 4 * hi;
+                                if (d0 < DH) {
+                                    f32x4 w;
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) w[i] = o[vb][qi][mt][rg * 4 + i];
+                                    *reinterpret_cast<f32x4*>(row_ptr(vb) + d0) = w;
+                                }
+                            }
+                }
+                if (hi == 0) {
+#pragma unroll
+                    for (int vb = 0; vb < NB; ++vb) {
+                        row_ptr(vb)[DH] = l_tot;
+                        row_ptr(vb)[DH + 1] = lshift;
+                    }
+                }
+            }
+        } else if (PACK && q_ok[qi]) {
             E* op0 = reinterpret_cast<E*>(p.out) + (((int64_t)b * Kq + f) * S + q_row[qi]) * ((int64_t)H * DH) + h * DH;
             const int64_t branch = (int64_t)Kq * S * H * DH;
 #pragma unroll
@@ -585,6 +644,59 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
             }
         }
     }
+}
+
+// Split form, second step: out = sum_seg O_seg 2^(sh_seg - M) / sum_seg l_seg 2^(sh_seg - M), M = max_seg sh_seg.
+// One thread per (bank, frame, head, query, 4 consecutive d).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ partials,
+                                                         typename T::elem* __restrict__ out, int Kq, int S, int H,
+                                                         int DH, int nseg) {
+    typedef typename T::elem E;
+    typedef typename T::vec4 vec4;
+    const int PS = DH + 8, dq = DH >> 2;
+    const int64_t total = (int64_t)2 * Kq * H * S * dq;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+        const int64_t R = g / dq;                 // ((vbank*Kq + f)*H + h)*S + q
+        const int d0 = (int)(g - R * dq) * 4;
+        const float* pr = partials + R * nseg * PS;
+        float M = -INFINITY;
+        for (int sg = 0; sg < nseg; ++sg) M = fmaxf(M, pr[sg * PS + DH + 1]);
+        f32x4 num = {0.f, 0.f, 0.f, 0.f};
+        float den = 0.f;
+        for (int sg = 0; sg < nseg; ++sg) {
+            const float w = __builtin_amdgcn_exp2f(pr[sg * PS + DH + 1] - M);
+            const f32x4 o4 = *reinterpret_cast<const f32x4*>(pr + sg * PS + d0);
+            num += o4 * w;
+            den = fmaf(pr[sg * PS + DH], w, den);
+        }
+        const float inv = 1.0f / den;
+        const int q = (int)(R % S);
+        int64_t t = R / S;
+        const int h = (int)(t % H);
+        t /= H;
+        const int f = (int)(t % Kq), vbank = (int)(t / Kq);
+        vec4 w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (E)(num[i] * inv);
+        E* op = out + (((int64_t)(1 + vbank) * Kq + f) * S + q) * ((int64_t)H * DH) + h * DH + d0;
+        *reinterpret_cast<u32x2*>(op) = __builtin_bit_cast(u32x2, w);
+    }
+}
+
+// How many runs of bank frames a bank problem is split into.  The grid of a sharded rank or of a small level has
+// too few waves to fill the chip (8-GPU rank at cfg2 level 0: 2 waves per SIMD, level 1: 0.5; single GPU at the
+// 16x16 level: 1): split until it has `occ` waves per SIMD, while a run keeps at least 2 tiles.
+static int split_plan(int K, int Kq, int S, int H, int Dh, bool inject, bool exact_scale, int part, bool allow) {
+    if (!allow || part == TF_ATTN_SOURCE_ONLY) return 1;
+    const bool dual = inject && S >= 256 && Dh != 160;
+    const int occ = Dh == 40 ? (dual ? 3 : 4) : Dh == 160 ? 1 : (dual ? 2 : 3);   // waves per SIMD the kernels reach
+    const int64_t wgs = (int64_t)(dual ? 1 : 2) * Kq * ((S + 127) / 128) * H;   // 4-wave workgroups
+    const int tpf = (S + 63) / 64;
+    int nseg = 1;
+    while (wgs * 4 * nseg < (int64_t)occ * 1024 && nseg * 2 <= K && (K / (nseg * 2)) * tpf >= 2) nseg *= 2;
+    (void)exact_scale;
+    return nseg;
 }
 
 // MFMA issue order of one ping-pong region: round-robin over the independent accumulators
@@ -1000,7 +1112,9 @@ int launch_one(AttnParams p, hipStream_t st) {
     p.nQT = (p.S + 32 * QT * NW - 1) / (32 * QT * NW);
     const int per_branch = p.Kq * p.nQT * p.H;
     // bank problems are decoded first: a bank-only launch simply stops before the source problems
-    const unsigned grid = (unsigned)(MODE == MODE_ALL ? (p.part == TF_ATTN_BANK_ONLY ? 2 : 3) * per_branch : per_branch);
+    const int ns = MODE == MODE_SOURCE ? 1 : p.nseg;
+    const unsigned grid = (unsigned)(MODE == MODE_ALL ? (2 * ns + (p.part == TF_ATTN_BANK_ONLY ? 0 : 1)) * per_branch
+                                                      : ns * per_branch);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, p);
     TF_LAUNCH_CHECK("tf_ext_attn_fwd");
     return 0;
@@ -1030,16 +1144,29 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
     // uncond + cond share QK^T and the softmax; pays from S = 256 on) and SOURCE (the source branch alone).
     // A full call is ALL, or DUAL followed by SOURCE; a bank-only call drops the source part, a source-only
     // call is SOURCE alone.
+    auto merge = [&]() -> int {   // split form: fold the per-run partial results into the output
+        if (p.nseg <= 1) return 0;
+        const int64_t total = (int64_t)2 * p.Kq * p.H * p.S * (DH / 4);
+        const int64_t blocks = (total + 255) / 256;
+        hipLaunchKernelGGL(attn_merge_kernel<T>, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st,
+                           p.partials, reinterpret_cast<E*>(p.out), p.Kq, p.S, p.H, DH, p.nseg);
+        TF_LAUNCH_CHECK("tf_ext_attn_fwd(merge)");
+        return 0;
+    };
     auto compose = [&](auto all, auto dual, auto source) -> int {
         if (src_only) return source();
-        if (!p.inject || p.S < 256) return all();   // short frames: the ALL form reads the source q, k itself
-        const int rc = dual();
+        if (!p.inject || p.S < 256) {   // short frames: the ALL form reads the source q, k itself
+            const int rc = all();
+            return rc ? rc : merge();
+        }
+        int rc = dual();
+        if (!rc) rc = merge();
         return (rc || bank_only) ? rc : source();
     };
     if constexpr (DH == 40) {
         // 8-wave (256-query) workgroups only while they still give >= 4 workgroups per CU; a sharded rank with
         // few query frames or heads takes the 4-wave form (twice the workgroups).  S < 256: always 4 waves.
-        const bool big = p.S >= 256 && (int64_t)3 * p.Kq * ((p.S + 255) / 256) * p.H >= 1024;
+        const bool big = p.nseg == 1 && p.S >= 256 && (int64_t)3 * p.Kq * ((p.S + 255) / 256) * p.H >= 1024;
         if (p.exact_scale)   // fp32 score scaling (TF_ATTN_EXACT_SCALE)
             return compose([&] { return big ? launch_one<T, DH, 1, 8, MODE_ALL, 2, false>(p, st)
                                             : launch_one<T, DH, 1, 4, MODE_ALL, 2, false>(p, st); },
@@ -1052,7 +1179,7 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
                        [&] { return big ? launch_one<T, DH, 1, 8, MODE_SOURCE, 2>(p, st)
                                         : launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st); });
     } else if constexpr (DH == 64) {
-        return compose([&] { return p.S >= 512 ? launch_pp<T, DH, MODE_ALL, 2>(p, st)   // ping-pong: +8..11 %
+        return compose([&] { return (p.S >= 512 && p.nseg == 1) ? launch_pp<T, DH, MODE_ALL, 2>(p, st)   // ping-pong: +8..11 %
                                                : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st); },
                        [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st); },
                        [&] { return launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st); });
@@ -1064,7 +1191,8 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
         // Dh=160: the dual (shared-softmax) form needs 160 more accumulator registers and measured slower;
         // under injection the ALL form reads the source q and k for every branch instead
         if (src_only) return launch_one<T, DH, 1, 4, MODE_SOURCE, 1>(p, st);
-        return launch_one<T, DH, 1, 4, MODE_ALL, 1>(p, st);
+        const int rc = launch_one<T, DH, 1, 4, MODE_ALL, 1>(p, st);
+        return rc ? rc : merge();
     }
 }
 
@@ -1084,7 +1212,16 @@ int dispatch_dh(int Dh, const AttnParams& p, const void* v, hipStream_t st) {
 extern "C" size_t tf_ext_attn_workspace_bytes(int K, int S, int H, int Dh, int dtype) {
     if (K <= 0 || S <= 0 || H <= 0 || Dh <= 0 || dtype == TF_F32) return 0;
     const size_t Spad = (size_t)((S + 127) / 128) * 128;   // frames padded to the largest staged tile
-    return ((vt_bytes(K, (int)Spad, H, Dh) + 255) & ~(size_t)255) + (size_t)3 * H * K * (Spad / 64) * sizeof(float);   // V^T image | key norm bounds
+    size_t part_elems = 0;   // split form: worst case over the number of query frames a caller may pass
+    for (int Kq = 1; Kq <= K; ++Kq)
+        for (int inj = 0; inj < 2; ++inj) {
+            const int ns = split_plan(K, Kq, S, H, Dh, inj != 0, false, 0, true);
+            const size_t e = ns > 1 ? (size_t)2 * Kq * H * S * ns * (Dh + 8) : 0;
+            part_elems = e > part_elems ? e : part_elems;
+        }
+    return ((vt_bytes(K, (int)Spad, H, Dh) + 255) & ~(size_t)255) +
+           (((size_t)3 * H * K * (Spad / 64) * sizeof(float) + 255) & ~(size_t)255) +
+           part_elems * sizeof(float);   // V^T image | key norm bounds | split-form partial results
 }
 
 extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void* out, int K, int Kq, int q_frame0,
@@ -1118,6 +1255,10 @@ extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void
     p.nQT = (S + 127) / 128;
     p.inject = (inject & TF_ATTN_INJECT) ? 1 : 0;
     p.part = inject & (TF_ATTN_BANK_ONLY | TF_ATTN_SOURCE_ONLY);
+    p.nseg = split_plan(K, Kq, S, H, Dh, p.inject != 0, p.exact_scale != 0, p.part, !(inject & TF_ATTN_NO_SPLIT));
+    p.partials = reinterpret_cast<float*>(
+        reinterpret_cast<unsigned char*>(const_cast<float*>(p.knorm2)) +
+        (((size_t)3 * H * K * (((S + 127) / 128) * 128 / 64) * sizeof(float) + 255) & ~(size_t)255));
     TF_ARG(p.part != (TF_ATTN_BANK_ONLY | TF_ATTN_SOURCE_ONLY), TF_ERR_SHAPE,
            "tf_ext_attn_fwd: TF_ATTN_BANK_ONLY and TF_ATTN_SOURCE_ONLY exclude each other");
     p.exact_scale = (inject & TF_ATTN_EXACT_SCALE) ? 1 : 0;

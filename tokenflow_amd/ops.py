@@ -40,6 +40,10 @@ def _workspace(nbytes: int, device, tag: str = "attn") -> torch.Tensor:
 
 # TOKENFLOW_EXACT_SCALE=1: fp32 scaling of the attention scores at head dim 40 (default: scale folded into q)
 EXACT_SCALE = os.environ.get("TOKENFLOW_EXACT_SCALE", "0") not in ("", "0")
+# TOKENFLOW_ATTN_NO_SPLIT=1: never split a bank problem over workgroups.  By default small grids (a sharded rank, the
+# 16x16 level) split the bank into runs of frames and merge; the merge re-associates fp32 sums, so results then
+# depend on the grid size in the last bits.  With the flag the arithmetic of a (query, head) is the same everywhere.
+NO_SPLIT = os.environ.get("TOKENFLOW_ATTN_NO_SPLIT", "0") not in ("", "0")
 
 
 def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float,
@@ -74,6 +78,8 @@ def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scal
         out = torch.empty(Bq, S, D, dtype=q.dtype, device=q.device)
     flags = (1 if inject else 0) | (2 if (EXACT_SCALE if exact_scale is None else exact_scale) else 0)
     flags |= {"all": 0, "bank": _lib.TF_ATTN_BANK_ONLY, "source": _lib.TF_ATTN_SOURCE_ONLY}[part]
+    if NO_SPLIT:
+        flags |= _lib.TF_ATTN_NO_SPLIT
     nbytes = lib.tf_ext_attn_workspace_bytes(K, S, heads, dh, dt)
     ws = _workspace(nbytes, q.device)
     _lib.check(lib.tf_ext_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), K, Kq, int(q_frame0),

@@ -32,7 +32,10 @@ MI355X; "gloo" in the CPU tests):
 
 Work is partitioned, not re-associated: every output element is produced by exactly the same
 kernel arithmetic as on one GPU (the attention of one (query, head) visits the K frames in the
-same order, whoever computes it), so sharded results equal single-process results bit for bit.
+same order, whoever computes it), so sharded results equal single-process results bit for bit --
+with one exception: the small grid of a rank makes `tf_ext_attn_fwd` split the bank over extra
+workgroups and merge, which re-associates fp32 sums; TOKENFLOW_ATTN_NO_SPLIT=1
+turns that off and restores bit-identical results.
 """
 from typing import Optional, Tuple
 
