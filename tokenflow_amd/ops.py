@@ -27,6 +27,7 @@ def compute_dtype(t: torch.Tensor) -> torch.dtype:
 
 
 _ws_cache = {}
+_attn_ws_bytes = {}   # (K, S, H, Dh, dtype) -> scratch bytes of tf_ext_attn_fwd (a pure function of the shape)
 
 
 def _workspace(nbytes: int, device, tag: str = "attn") -> torch.Tensor:
@@ -80,7 +81,10 @@ def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scal
     flags |= {"all": 0, "bank": _lib.TF_ATTN_BANK_ONLY, "source": _lib.TF_ATTN_SOURCE_ONLY}[part]
     if NO_SPLIT:
         flags |= _lib.TF_ATTN_NO_SPLIT
-    nbytes = lib.tf_ext_attn_workspace_bytes(K, S, heads, dh, dt)
+    key = (K, S, heads, dh, dt)
+    nbytes = _attn_ws_bytes.get(key)
+    if nbytes is None:
+        nbytes = _attn_ws_bytes[key] = lib.tf_ext_attn_workspace_bytes(K, S, heads, dh, dt)
     ws = _workspace(nbytes, q.device)
     _lib.check(lib.tf_ext_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), K, Kq, int(q_frame0),
                                    S, heads, dh,
