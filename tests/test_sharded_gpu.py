@@ -77,3 +77,40 @@ def test_sharded_real_kernels_two_ranks(K, mode, inject, no_split):
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, K, inject, mode, no_split, ret), nprocs=2, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def _rccl_worker(rank, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from tokenflow_amd import ops, sharded
+        ops.NO_SPLIT = True
+        K, S, h, d = 3, 320, 2, 40
+        g = torch.Generator().manual_seed(3)
+        q, k, v = (torch.randn(3 * K, S, h * d, generator=g).bfloat16().cuda() for _ in range(3))
+        sh = sharded.FrameShard(K)
+        ok = True
+        for inject in (False, True):
+            full = ops.ext_attn(q, k, v, h, d ** -0.5, inject)
+            out = sh._pivotal_heads(q, k, v, h, d ** -0.5, inject)      # the all-to-alls run through RCCL
+            ok = ok and torch.equal(out, full)
+            kb, vb = sh.gather_bank(q, k, inject)                        # world 1: returns its inputs
+            ok = ok and kb is q
+        pe, ie, ke = sh.exchange_halo(q[:K], torch.ones(K, S, device="cuda"), full)
+        ok = ok and pe is q[:K] or pe.data_ptr() == q.data_ptr()
+        torch.cuda.synchronize()
+        ret[0] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_head_exchange_through_rccl_single_rank():
+    """The same torch.distributed calls the multi-GPU run makes (all_to_all_single with async_op, default splits),
+    on the real backend: RCCL ("nccl") with a world of one GPU -- all the pool offers.  Catches API-level
+    mistakes that the gloo tests cannot (argument forms, device tensors, stream ordering)."""
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_worker, args=(port, ret), nprocs=1, join=True)
+    assert dict(ret) == {0: True}
