@@ -693,6 +693,7 @@ static int split_plan(int K, int Kq, int S, int H, int Dh, bool inject, bool exa
     const int occ = Dh == 40 ? (dual ? 3 : 4) : Dh == 160 ? 1 : (dual ? 2 : 3);   // waves per SIMD the kernels reach
     const int64_t wgs = (int64_t)(dual ? 1 : 2) * Kq * ((S + 127) / 128) * H;   // 4-wave workgroups
     const int tpf = (S + 63) / 64;
+    if (K * tpf < 16) return 1;   // a bank of a few tiles: the merge launch costs more than it buys (8x8 level)
     int nseg = 1;
     while (wgs * 4 * nseg < (int64_t)occ * 1024 && nseg * 2 <= K && (K / (nseg * 2)) * tpf >= 2) nseg *= 2;
     (void)exact_scale;
@@ -1164,9 +1165,10 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
         return (rc || bank_only) ? rc : source();
     };
     if constexpr (DH == 40) {
-        // 8-wave (256-query) workgroups only while they still give >= 4 workgroups per CU; a sharded rank with
-        // few query frames or heads takes the 4-wave form (twice the workgroups).  S < 256: always 4 waves.
-        const bool big = p.nseg == 1 && p.S >= 256 && (int64_t)3 * p.Kq * ((p.S + 255) / 256) * p.H >= 1024;
+        // 8-wave (256-query) workgroups while they still give 3 workgroups per CU (split runs included: measured
+        // -8..11 % on a sharded rank's level 0 against the 4-wave form); below that the 4-wave form (twice the
+        // workgroups).  S < 256: always 4 waves.
+        const bool big = p.S >= 256 && (int64_t)3 * p.Kq * ((p.S + 255) / 256) * p.H * p.nseg >= 768;
         if (p.exact_scale)   // fp32 score scaling (TF_ATTN_EXACT_SCALE)
             return compose([&] { return big ? launch_one<T, DH, 1, 8, MODE_ALL, 2, false>(p, st)
                                             : launch_one<T, DH, 1, 4, MODE_ALL, 2, false>(p, st); },
