@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TF_ABI_VERSION 1
+#define TF_ABI_VERSION 2
 
 /* element types */
 #define TF_BF16 0
@@ -43,6 +43,7 @@ extern "C" {
 #define TF_ATTN_BANK_ONLY 4    /* compute only the uncond and cond branches (those that read the K-frame bank) */
 #define TF_ATTN_SOURCE_ONLY 8  /* compute only the source branch (own-frame keys) */
 #define TF_ATTN_NO_SPLIT 16    /* never split a bank problem over workgroups (one pass, bit-stable across grid sizes) */
+#define TF_ATTN_OUT_F32 32     /* `out` is float: the normalised fp32 accumulator, without the rounding to the 16-bit I/O type */
 
 /* argument errors */
 #define TF_ERR_NULL (-1)
@@ -67,7 +68,7 @@ const char* tf_last_error(void);
  *                               Single GPU: Kq = K, q_frame0 = 0 (q is the reference's q).
  *                               Frame-sharded multi-GPU: a rank passes its own keyframes' q
  *                               and the all-gathered bank.
- *   out     : [3, Kq, S, H*Dh]  dense, same dtype
+ *   out     : [3, Kq, S, H*Dh]  dense, same dtype (float with TF_ATTN_OUT_F32)
  *   source branch: frame f attends to its own S keys (lines 173,177);
  *   uncond / cond: frame f attends to all K*S keys of its branch (133-138,
  *   174-179) -- the bank is read in place, never replicated.
@@ -88,6 +89,10 @@ const char* tf_last_error(void);
  *   Small grids (a sharded rank, the coarse levels) split every bank problem into runs of bank frames over
  *   extra workgroups and merge the partial results (fp32) in a second launch; TF_ATTN_NO_SPLIT keeps the
  *   one-pass form, whose arithmetic per (query, head) does not depend on the grid.
+ *
+ *   inject & TF_ATTN_OUT_F32: `out` is float [3, Kq, S, H*Dh]; the softmax-normalised fp32 accumulator is stored
+ *   as is.  Removes the output rounding (2^-9 relative for bf16) from the result: the mode in which the
+ *   "< 1e-3 per token" target of BASELINE.json holds for outputs of any magnitude.
  *
  *   ws: scratch for the transposed V bank (+ key norms, + split-form partials); size from
  *   tf_ext_attn_workspace_bytes.
@@ -161,6 +166,29 @@ int tf_nn_gather_blend(const void* tgt, const void* piv, const float* inv_norm,
                        int K, int n, int S, int D, int P, int kf0, int kf1,
                        int search_dtype, int in_dtype, int res_dtype, int out_dtype,
                        void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Propagation branch for a RUN of consecutive chunks in one call  --  tokenflow_utils.py:329-397 executed for
+ * C chunks at once.  The reference runs one UNet pass per chunk of n = batch_size frames
+ * (run_tokenflow_pnp.py:228-231) because a pass over all frames does not fit its GPUs; with 288 GB a caller can
+ * carry every chunk in one pass (or, as bench.py and the frame-sharded path do, simply owns all chunks' tensors),
+ * and the C searches + gathers become two launches whose grids are C times larger (no short tail round per chunk).
+ *
+ *   tgt    : [C*n*S, D]        norm_hidden_states[0], chunk-major (chunk j = rows j*n*S .. (j+1)*n*S-1)
+ *   resid, out : [3, C*n, S, D]
+ *   chunk j matches keyframe slots slot0 + j and slot0 + j - 1 of piv / inv_norm / kf_out ([.., K, ..]; the reference
+ *   order [i, i-1], 331-333).  first_single != 0: chunk 0 of the call is chunk 0 of the video and matches slot0
+ *   alone (line 390); its rows are rounded to `single_dtype` -- the dtype the reference's pass produces for that
+ *   chunk, torch promotion of the cached output and hidden_states -- before being stored as `out_dtype`.
+ *   Results are bit-identical to C calls of tf_nn_gather_blend.  C = 1 with first_single is tf_nn_gather_blend(P = 1).
+ *   w : float [n], as tf_gather_blend.
+ * ------------------------------------------------------------------------ */
+size_t tf_nn_gather_blend_chunks_workspace_bytes(int64_t n_tgt_chunk, int S, int D, int C);
+
+int tf_nn_gather_blend_chunks(const void* tgt, const void* piv, const float* inv_norm, const void* kf_out,
+                              const float* w, const void* resid, void* out, int K, int n, int C, int S, int D,
+                              int slot0, int first_single, int search_dtype, int in_dtype, int res_dtype,
+                              int out_dtype, int single_dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Row LayerNorm producer  --  the `norm1` call of TokenFlowBlock.forward

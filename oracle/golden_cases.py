@@ -87,3 +87,33 @@ def blocks_inputs(t):
                 pivotal=hid(K), chunks=[hid(n) for _ in range(cfg["n_chunks"])],
                 res_x=torch.randn(3 * n, cfg["dims"][2], 4, 4, generator=g),
                 res_temb=torch.randn(3 * n, 16, generator=g))
+
+
+ADAZERO_CFG = dict(dim=80, heads=2, cross_dim=32, K=3, n=2, S=24, seed=977, timestep=481.0)
+
+
+def adazero_block():
+    """A BasicTransformerBlock whose norm1 is an AdaLayerNormZero (use_ada_layer_norm_zero = True): the block
+    type the reference gates with gate_msa in BOTH passes (tokenflow_utils.py:365-366)."""
+    from tests import fake_diffusers as fd
+    cfg = ADAZERO_CFG
+    torch.manual_seed(cfg["seed"])
+    blk = fd.BasicTransformerBlock(cfg["dim"], cfg["heads"], cross_dim=cfg["cross_dim"])
+    blk.norm1 = fd.AdaLayerNormZero(cfg["dim"])
+    blk.use_ada_layer_norm_zero = True
+    return blk.eval()
+
+
+def adazero_inputs():
+    cfg = ADAZERO_CFG
+    K, n, S, D = cfg["K"], cfg["n"], cfg["S"], cfg["dim"]
+    g = torch.Generator().manual_seed(cfg["seed"] + 1)
+    x_piv = torch.randn(3 * K, S, D, generator=g)
+    chunks = []
+    for c in range(K):       # video-like source branch: permuted keyframe tokens + noise (far from NN ties)
+        perm = torch.randperm(S, generator=g)
+        src = x_piv.view(3, K, S, D)[0, c][perm][None].repeat(n, 1, 1) + 0.05 * torch.randn(n, S, D, generator=g)
+        chunks.append(torch.cat([src, torch.randn(2 * n, S, D, generator=g)]))
+    return dict(pivotal=x_piv, chunks=chunks, enc=torch.randn(3 * K, 7, cfg["cross_dim"], generator=g),
+                enc_n=torch.randn(3 * n, 7, cfg["cross_dim"], generator=g),
+                timestep=torch.tensor([cfg["timestep"]]))

@@ -23,6 +23,9 @@ Fixtures
                  per-block outputs of the pivotal pass and of chunks 0..2, and the
                  patched resnet forward.  Module weights come from a seed; a
                  checksum guards against RNG drift.
+  adazero.pt     TokenFlowBlock.forward on an AdaLayerNormZero block (use_ada_layer_norm_zero:
+                 gate_msa on the cached / selected attention outputs, 362-366; scale/shift/gate
+                 on the feed-forward, 417-424): pivotal pass and chunks 0..K-1.
 """
 import os
 import zlib
@@ -175,12 +178,35 @@ def gen_blocks(tfu):
     return out
 
 
+def gen_adazero(tfu):
+    """TokenFlowBlock on an AdaLayerNormZero block: pivotal pass, then chunks 0..K-1 (gate_msa applied to the
+    selected keyframe outputs before the gather, tokenflow_utils.py:362-366)."""
+    blk = gc.adazero_block()
+    holder = _OneBlock(blk)
+    tfu.register_extended_attention_pnp(holder, [])
+    tfu.set_tokenflow(holder.unet)
+    blk.attn1.t = blk.attn2.t = 7
+    inp = gc.adazero_inputs()
+    out = dict(weights_checksum=gc.checksum(*blk.parameters()),
+               input_checksum=gc.checksum(inp["pivotal"], *inp["chunks"]), chunks=[])
+    with torch.no_grad():
+        tfu.register_pivotal(holder, True)
+        out["pivotal"] = digest(blk(inp["pivotal"], encoder_hidden_states=inp["enc"], timestep=inp["timestep"]), 7)
+        tfu.register_pivotal(holder, False)
+        for c in range(gc.ADAZERO_CFG["K"]):
+            tfu.register_batch_idx(holder, c)
+            out["chunks"].append(digest(blk(inp["chunks"][c], encoder_hidden_states=inp["enc_n"],
+                                            timestep=inp["timestep"]), 7))
+    return out
+
+
 def main():
     tfu, util = ref_loader.load()
     os.makedirs(GOLDEN, exist_ok=True)
     torch.save(gen_attn_core(tfu), os.path.join(GOLDEN, "attn_core.pt"))
     torch.save(gen_propagate(tfu, util), os.path.join(GOLDEN, "propagate.pt"))
     torch.save(gen_blocks(tfu), os.path.join(GOLDEN, "blocks.pt"))
+    torch.save(gen_adazero(tfu), os.path.join(GOLDEN, "adazero.pt"))
     for f in sorted(os.listdir(GOLDEN)):
         print(f, os.path.getsize(os.path.join(GOLDEN, f)) // 1024, "KiB")
 

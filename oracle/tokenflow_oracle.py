@@ -222,23 +222,41 @@ class BlockState:
 
 def block_forward(block, state: BlockState, hidden_states: torch.Tensor, *, pivotal: bool,
                   batch_idx: int = 0, inject: bool = False,
-                  encoder_hidden_states: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  encoder_hidden_states: Optional[torch.Tensor] = None, timestep=None,
+                  class_labels=None) -> torch.Tensor:
     """`TokenFlowBlock.forward` for a plain-LayerNorm block (the SD case:
-    use_ada_layer_norm* False, only_cross_attention False)."""
+    use_ada_layer_norm* False, only_cross_attention False) and for an
+    AdaLayerNormZero block (317-320, 365-366, 417-424)."""
     B, S, D = hidden_states.shape
     n = B // 3
-    norm = block.norm1(hidden_states.view(3, n, S, D)).view(3, n, S, D)     # 314-325
+    zero = bool(getattr(block, "use_ada_layer_norm_zero", False))
+    if zero:                                                                 # 317-320
+        norm, gate_msa, shift_mlp, scale_mlp, gate_mlp = block.norm1(
+            hidden_states.view(3, n, S, D), timestep, class_labels, hidden_dtype=hidden_states.dtype)
+    else:
+        norm = block.norm1(hidden_states.view(3, n, S, D))                   # 314-325
+    norm = norm.view(3, n, S, D)
     if pivotal:
         state.pivot_hidden_states = norm                                     # 326-327
         attn_output = sa_forward(block.attn1, norm.view(B, S, D), inject)    # 352-358
         state.kf_attn_output = attn_output                                   # 360
+        if zero:
+            attn_output = gate_msa.unsqueeze(1) * attn_output                # 365-366
     else:
         idx, _ = nn_search(norm[0], state.pivot_hidden_states[0], batch_idx)  # 329-348
-        attn_output = gather_blend(state.kf_attn_output, idx, batch_idx, n)    # 361-393
+        kf = state.kf_attn_output
+        if zero:   # 362-366: the gate multiplies the selected keyframes' outputs; gating all K is the same numbers
+            K = kf.shape[0] // 3
+            kf = (gate_msa.unsqueeze(1) * kf.view(3, K, S, D)).reshape(3 * K, S, D)
+        attn_output = gather_blend(kf, idx, batch_idx, n)                    # 361-393
     h = attn_output + hidden_states.reshape(B, S, D)                         # 396-397
     if block.attn2 is not None:                                              # 399-411
         h = block.attn2(block.norm2(h), encoder_hidden_states=encoder_hidden_states) + h
-    return block.ff(block.norm3(h)) + h                                      # 413-425
+    nh = block.norm3(h)                                                      # 413-425
+    if zero:
+        nh = nh * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
+        return gate_mlp.unsqueeze(1) * block.ff(nh) + h
+    return block.ff(nh) + h
 
 
 # ---------------------------------------------------------------------------

@@ -82,6 +82,26 @@ class BasicTransformerBlock(nn.Module):
         return self.ff(self.norm3(h)) + h
 
 
+class AdaLayerNormZero(nn.Module):
+    """`norm1` of an AdaLayerNormZero block as TokenFlowBlock.forward consumes it
+    (/root/reference/tokenflow_utils.py:317-320): norm1(x, timestep, class_labels, hidden_dtype=) ->
+    (x, gate_msa, shift_mlp, scale_mlp, gate_mlp), diffusers' contract, with a ONE-row conditioning embedding
+    (the only batch shape for which the reference's 4-D hidden_states broadcast at all)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.emb = nn.Linear(1, dim)
+        self.silu = nn.SiLU()
+        self.linear = nn.Linear(dim, 6 * dim)
+        self.norm = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
+
+    def forward(self, x, timestep, class_labels=None, hidden_dtype=None):
+        emb = self.linear(self.silu(self.emb(timestep.reshape(-1, 1).float())))
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = emb.chunk(6, dim=1)
+        x = self.norm(x) * (1 + scale_msa[:, None]) + shift_msa[:, None]
+        return x, gate_msa, shift_mlp, scale_mlp, gate_mlp
+
+
 class Transformer2DModel(nn.Module):
     def __init__(self, dim, heads, cross_dim=32):
         super().__init__()

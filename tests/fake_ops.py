@@ -23,7 +23,8 @@ class FakeOps:
     def compute_dtype(self, t):
         return t.dtype
 
-    def ext_attn(self, q, k, v, heads, scale, inject, out=None, q_frame0=0, exact_scale=None, part="all"):
+    def ext_attn(self, q, k, v, heads, scale, inject, out=None, q_frame0=0, exact_scale=None, part="all",
+                 out_dtype=None):
         self.calls.append(("ext_attn", tuple(q.shape), bool(inject)) + ((part,) if part != "all" else ()))
         K, Kq = k.shape[0] // 3, q.shape[0] // 3
         qf, kf, vf = self._r(q).clone(), self._r(k).clone(), self._r(v).clone()
@@ -47,7 +48,7 @@ class FakeOps:
             o.view(3, -1)[[0] if part == "bank" else [1, 2]] = float("nan")
         if Kq != K:
             o = o.view(3, K, *q.shape[1:])[:, q_frame0:q_frame0 + Kq].reshape(3 * Kq, *q.shape[1:])
-        o = self._r(o).to(q.dtype)
+        o = o.float() if out_dtype == torch.float32 else self._r(o).to(q.dtype)
         if out is None:
             return o
         computed = {"all": [0, 1, 2], "bank": [1, 2], "source": [0]}[part]
@@ -84,6 +85,24 @@ class FakeOps:
 
     def propagate(self, tgt, piv, inv_norm, kf_ids, kf_out, w, n, residual, out_dtype):
         return self.gather_blend(kf_out, self.nn_search(tgt, piv, inv_norm, kf_ids), w, kf_ids, n, residual, out_dtype)
+
+    def propagate_chunks(self, tgt, piv, inv_norm, kf_out, w, n, n_chunks, slot0, first_single, residual, out_dtype):
+        """C chunks in one call = C calls of `propagate`, outputs interleaved back to [3, C*n, S, D]; the
+        one-keyframe chunk is rounded to the dtype its own call would have produced."""
+        S, D = piv.shape[1:]
+        res = residual.view(3, n_chunks, n, S, D) if residual is not None else None
+        outs = []
+        for j in range(n_chunks):
+            single = first_single and j == 0
+            ids = [slot0 + j] if single else [slot0 + j, slot0 + j - 1]
+            r = res[:, j].reshape(3 * n, S, D) if res is not None else None
+            dt = out_dtype
+            if single:
+                dt = kf_out.dtype if r is None else torch.promote_types(kf_out.dtype, r.dtype)
+            o = self.propagate(tgt[j * n * S:(j + 1) * n * S], piv, inv_norm, ids, kf_out, None if single else w,
+                               n, r, dt)
+            outs.append(o.to(out_dtype).view(3, n, S, D))
+        return torch.stack(outs, dim=1).reshape(3 * n_chunks * n, S, D)
 
     def inject_copy_(self, x):
         self.calls.append(("inject_copy_", tuple(x.shape)))

@@ -149,6 +149,127 @@ def test_propagation_dtype_promotion(fake_ops):
         assert seen["dtype"] == torch.float32
 
 
+def test_adazero_block_matches_reference_golden(fake_ops):
+    """AdaLayerNormZero blocks: the propagation pass gates the selected keyframe outputs with gate_msa before
+    the gather, as the reference does (tokenflow_utils.py:362-366) -- pinned to the verbatim reference."""
+    from tests.conftest import load_golden
+    g = load_golden("adazero.pt")
+    blk = gc.adazero_block()
+    assert gc.checksum(*blk.parameters()) == g["weights_checksum"], "RNG drift"
+    holder = torch.nn.Module()
+    holder.unet = torch.nn.Module()
+    holder.unet.blk = blk
+    blk.attn1.forward = hooks._make_sa_forward(blk.attn1, pnp=True)
+    hooks._set_schedule(blk.attn1, [])
+    blk.attn1.t = 7
+    tfu.set_tokenflow(holder)
+    inp = gc.adazero_inputs()
+    with torch.no_grad():
+        tfu.register_pivotal(holder, True)
+        check(blk(inp["pivotal"], encoder_hidden_states=inp["enc"], timestep=inp["timestep"]), g["pivotal"], 3e-5,
+              "adazero/pivotal")
+        tfu.register_pivotal(holder, False)
+        for c in range(gc.ADAZERO_CFG["K"]):
+            tfu.register_batch_idx(holder, c)
+            check(blk(inp["chunks"][c], encoder_hidden_states=inp["enc_n"], timestep=inp["timestep"]),
+                  g["chunks"][c], 3e-5, f"adazero/chunk{c}")
+
+
+@pytest.mark.parametrize("first", [0, 1])
+def test_multi_chunk_pass_equals_per_chunk_passes(fake_ops, first):
+    """Extension: `batch_idx` may be a run of consecutive chunks carried by ONE pass (frames chunk-major inside
+    each branch).  The block output must equal the per-chunk passes of the reference API, row for row."""
+    cfg = gc.BLOCKS_CFG
+    pipe = _pipe()
+    tfu.register_extended_attention_pnp(pipe, [])
+    tfu.set_tokenflow(pipe.unet)
+    tfu.register_time(pipe, 1)
+    K, n, S, D = 4, 2, 16, cfg["dims"][0]
+    blk = pipe.unet.down_blocks[0].attentions[0].transformer_blocks[0]
+    g = torch.Generator().manual_seed(5)
+    enc, enc_n = torch.randn(3 * K, 7, 32, generator=g), torch.randn(3 * n, 7, 32, generator=g)
+    chunks = [torch.randn(3 * n, S, D, generator=g) for _ in range(K)]
+    with torch.no_grad():
+        tfu.register_pivotal(pipe, True)
+        blk(torch.randn(3 * K, S, D, generator=g), encoder_hidden_states=enc)
+        tfu.register_pivotal(pipe, False)
+        ref = []
+        for c in range(first, K):
+            tfu.register_batch_idx(pipe, c)
+            ref.append(blk(chunks[c], encoder_hidden_states=enc_n).view(3, n, S, D))
+        C = K - first
+        x_all = torch.stack([chunks[c].view(3, n, S, D) for c in range(first, K)], dim=1).reshape(3 * C * n, S, D)
+        tfu.register_batch_idx(pipe, range(first, K))
+        got = blk(x_all, encoder_hidden_states=enc_n.view(3, n, 7, 32).repeat(1, C, 1, 1).reshape(3 * C * n, 7, 32))
+    want = torch.stack(ref, dim=1).reshape(3 * C * n, S, D)
+    assert got.dtype == want.dtype and torch.allclose(got, want, atol=1e-6, rtol=0)
+    with pytest.raises(ValueError):
+        tfu.register_batch_idx(pipe, [0, 2])
+        blk(x_all, encoder_hidden_states=enc_n)
+
+
+def test_fused_qkv_equals_three_projections(fake_ops, monkeypatch):
+    """Row f2: q, k, v as column slabs of one GEMM against the cached concatenated weight -- on CPU the fused
+    path is disabled (x.is_cuda), so emulate it by calling the helper's math directly: the slabs must equal the
+    three Linear outputs bit for bit (same dot products, same fp32 accumulation order per output column)."""
+    attn = fd.Attention(80, 2).eval()
+    x = torch.randn(6, 16, 80)
+    wcat = torch.cat([attn.to_q.weight, attn.to_k.weight, attn.to_v.weight], 0)
+    qkv = torch.nn.functional.linear(x, wcat)
+    for i, lin in enumerate((attn.to_q, attn.to_k, attn.to_v)):
+        assert torch.allclose(qkv[..., 80 * i:80 * (i + 1)], lin(x), atol=1e-6, rtol=0)
+    assert hooks._fused_qkv(attn, x) is None            # CPU tensors: the caller issues the three projections
+
+
+def test_latents_cache_is_bounded(tmp_path):
+    for t in (981, 961, 941, 921):
+        torch.save(torch.full((2, 4, 8, 8), float(t)), tmp_path / f"noisy_latents_{t}.pt")
+    for t in (981, 961, 941, 921, 981):
+        assert float(tfu.load_source_latents_t(t, str(tmp_path))[0, 0, 0, 0]) == t
+    assert len(hooks._latents_cache) <= hooks._LATENTS_CACHE_ENTRIES
+
+
+def test_launcher_shadows_same_named_modules_in_the_script_directory(tmp_path):
+    """`python script.py` resolves `tokenflow_utils` / `util` to the script's OWN directory (sys.path[0] beats
+    PYTHONPATH): inside a reference checkout the drop-in would silently not be used.  The launcher must win."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    (tmp_path / "tokenflow_utils.py").write_text("def register_pivotal(m, p):\n    raise SystemExit('decoy used')\n")
+    (tmp_path / "util.py").write_text("def seed_everything(s):\n    raise SystemExit('decoy used')\n"
+                                      "save_video = None\n")
+    (tmp_path / "local_helper.py").write_text("VALUE = 41\n")
+    (tmp_path / "run_stub.py").write_text(
+        "import sys\n"
+        "from tokenflow_utils import *\n"
+        "from util import save_video, seed_everything\n"
+        "import local_helper\n"
+        "if __name__ == '__main__':\n"
+        "    print('ARGV', sys.argv[1:])\n"
+        "    print('MOD', register_pivotal.__module__, seed_everything.__module__, local_helper.VALUE)\n")
+    env = dict(os.environ, PYTHONPATH=root, TOKENFLOW_QUIET="1")
+    # the documented-but-wrong way: PYTHONPATH alone -> the decoy is imported
+    plain = subprocess.run([sys.executable, str(tmp_path / "run_stub.py")], cwd=tmp_path, env=env,
+                           capture_output=True, text=True)
+    assert "MOD tokenflow_utils util" in plain.stdout
+    # the launcher: this repository's modules, the script's other local imports intact, argv passed through
+    res = subprocess.run([sys.executable, "-m", "tokenflow_amd.run", str(tmp_path / "run_stub.py"), "--x", "1"],
+                         cwd=tmp_path, env=env, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert "ARGV ['--x', '1']" in res.stdout
+    assert "MOD tokenflow_amd.hooks util 41" in res.stdout
+
+
+def test_hook_installation_announces_the_hip_path(capsys, monkeypatch):
+    monkeypatch.setattr(hooks, "_announced", False)
+    monkeypatch.delenv("TOKENFLOW_QUIET", raising=False)
+    tfu.set_tokenflow(_pipe().unet)
+    assert "HIP hook path active" in capsys.readouterr().err
+    tfu.set_tokenflow(_pipe().unet)
+    assert capsys.readouterr().err == ""            # once per process
+
+
 def test_load_source_latents_cache(tmp_path):
     x = torch.randn(4, 4, 8, 8)
     torch.save(x, tmp_path / "noisy_latents_981.pt")
@@ -182,4 +303,4 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.tf_abi_version() == 1
+    assert lib.tf_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define TF_ABI_VERSION (\d+)", hdr).group(1))

@@ -3,6 +3,8 @@
 import pytest
 import torch
 
+from tests.conftest import load_golden
+
 from oracle import golden_cases as gc
 from oracle import tokenflow_oracle as orc
 from oracle.golden_util import check
@@ -88,3 +90,22 @@ def test_blocks_match_reference(golden_blocks):
             if orc.should_inject(t, cfg["conv_schedule"]):
                 orc.conv_inject_(h)
             check((x + h) / res.output_scale_factor, run["resnet"], 1e-6, f"t{t}/resnet")
+
+
+def test_oracle_adazero_block_matches_reference_golden():
+    """AdaLayerNormZero block (gate_msa in both passes, tokenflow_utils.py:365-366; scale/shift/gate on the
+    feed-forward, 417-424) against the verbatim reference's outputs."""
+    g = load_golden("adazero.pt")
+    blk = gc.adazero_block()
+    assert gc.checksum(*blk.parameters()) == g["weights_checksum"], "RNG drift"
+    inp = gc.adazero_inputs()
+    assert gc.checksum(inp["pivotal"], *inp["chunks"]) == g["input_checksum"]
+    st = orc.BlockState()
+    with torch.no_grad():
+        y = orc.block_forward(blk, st, inp["pivotal"], pivotal=True, encoder_hidden_states=inp["enc"],
+                              timestep=inp["timestep"])
+        check(y, g["pivotal"], 3e-5, "adazero/pivotal")
+        for c in range(gc.ADAZERO_CFG["K"]):
+            y = orc.block_forward(blk, st, inp["chunks"][c], pivotal=False, batch_idx=c,
+                                  encoder_hidden_states=inp["enc_n"], timestep=inp["timestep"])
+            check(y, g["chunks"][c], 3e-5, f"adazero/chunk{c}")

@@ -8,7 +8,8 @@ LIB_PATH = os.environ.get("TOKENFLOW_HIP_LIB") or os.path.join(_HERE, "libtokenf
 
 TF_BF16, TF_F16, TF_F32 = 0, 1, 2
 TF_ATTN_INJECT, TF_ATTN_EXACT_SCALE, TF_ATTN_BANK_ONLY, TF_ATTN_SOURCE_ONLY, TF_ATTN_NO_SPLIT = 1, 2, 4, 8, 16
-ABI_VERSION = 1
+TF_ATTN_OUT_F32 = 32
+ABI_VERSION = 2
 
 _c = ctypes
 _SIGNATURES = {
@@ -24,6 +25,9 @@ _SIGNATURES = {
     "tf_gather_blend": (_c.c_int, [_c.c_void_p] * 5 + [_c.c_int] * 10 + [_c.c_void_p]),
     "tf_nn_gather_blend_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int, _c.c_int]),
     "tf_nn_gather_blend": (_c.c_int, [_c.c_void_p] * 7 + [_c.c_int] * 11 + [_c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "tf_nn_gather_blend_chunks_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int, _c.c_int]),
+    "tf_nn_gather_blend_chunks": (_c.c_int, [_c.c_void_p] * 7 + [_c.c_int] * 12 + [_c.c_void_p, _c.c_size_t,
+                                             _c.c_void_p]),
     "tf_layer_norm": (_c.c_int, [_c.c_void_p] * 5 + [_c.c_int64, _c.c_int, _c.c_float] + [_c.c_int] * 3 + [_c.c_void_p]),
     "tf_inject_copy": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p]),
 }

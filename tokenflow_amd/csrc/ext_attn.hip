@@ -67,6 +67,7 @@ struct AttnParams {
     void* out;
     int K, Kq, q_frame0, S, H, Spad, nQT, inject, exact_scale;
     int part;  // 0 = all three branches, TF_ATTN_BANK_ONLY, TF_ATTN_SOURCE_ONLY
+    int out_f32;       // TF_ATTN_OUT_F32: `out` is float (the normalised fp32 accumulator, no 16-bit rounding)
     int nseg;          // > 1: every bank problem is split into nseg runs of bank frames (small grids, see split_plan)
     float* partials;   // [2 banks][Kq][H][S][nseg][Dh + 8] fp32: unnormalised O, l, log2-domain shift  // K bank frames; queries = frames q_frame0 .. +Kq
     int64_t ld;
@@ -86,6 +87,20 @@ __host__ __device__ __forceinline__ int64_t vt_row_stride(int K, int Spad) { ret
 
 static inline size_t vt_bytes(int K, int Spad, int H, int Dh) {
     return (size_t)3 * H * Dh * (size_t)vt_row_stride(K, Spad) * 2;
+}
+
+// 4 consecutive output features of one query: rounded to the 16-bit I/O type, or, with TF_ATTN_OUT_F32, the
+// normalised fp32 accumulator itself (the caller's `out` is then float [3,Kq,S,H*Dh])
+template <typename E, typename V4>
+__device__ __forceinline__ void store_out4(void* out, int64_t elem_off, f32x4 x, int out_f32) {
+    if (out_f32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + elem_off) = x;
+    } else {
+        V4 w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (E)x[i];
+        *reinterpret_cast<u32x2*>(reinterpret_cast<E*>(out) + elem_off) = __builtin_bit_cast(u32x2, w);
+    }
 }
 
 __device__ __forceinline__ int swap23(int x) { return (x & ~12) | ((x & 4) << 1) | ((x & 8) >> 1); }
@@ -468,7 +483,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
                         const float sh_old = m_run[qi];          // m_run holds the current shift (0 before tile 0)
                         const float sh_new = (first || mx > FOLD_T) ? (float)(E)(sh_old + mx) : sh_old;
                         delta = sh_new - sh_old;
-                        const float alpha = __builtin_amdgcn_exp2f(-delta);
+                        // first tile: O is still zero, and exp2(-delta) overflows to +inf when every score of the
+                        // tile is far below zero (0 * inf = NaN) -- nothing to rescale there
+                        const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
                         m_run[qi] = sh_new;
                         if (hi == SH_HI) qf[qi][SH_T][0] = (E)(-sh_new);
 #pragma unroll
@@ -609,7 +626,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
                 }
             }
         } else if (PACK && q_ok[qi]) {
-            E* op0 = reinterpret_cast<E*>(p.out) + (((int64_t)b * Kq + f) * S + q_row[qi]) * ((int64_t)H * DH) + h * DH;
+            const int64_t op0 = (((int64_t)b * Kq + f) * S + q_row[qi]) * ((int64_t)H * DH) + h * DH;
             const int64_t branch = (int64_t)Kq * S * H * DH;
 #pragma unroll
             for (int g = 0; g < 3; ++g)
@@ -618,27 +635,26 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
                     const int R = g * 32 + 8 * rg + 4 * hi;    // image row of this group of 4 (never straddles a bank)
                     if (R < NB * DH) {
                         const int vb = R >= DH ? 1 : 0;
-                        vec4 w;
+                        f32x4 w;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) w[i] = (E)(o[g >> 1][qi][g & 1][rg * 4 + i] * inv_l);
-                        *reinterpret_cast<u32x2*>(op0 + vb * branch + (R - vb * DH)) = __builtin_bit_cast(u32x2, w);
+                        for (int i = 0; i < 4; ++i) w[i] = o[g >> 1][qi][g & 1][rg * 4 + i] * inv_l;
+                        store_out4<E, vec4>(p.out, op0 + vb * branch + (R - vb * DH), w, p.out_f32);
                     }
                 }
         } else if (q_ok[qi]) {
 #pragma unroll
             for (int vb = 0; vb < NB; ++vb) {
-                E* op = reinterpret_cast<E*>(p.out) +
-                        (((int64_t)(b + vb) * Kq + f) * S + q_row[qi]) * ((int64_t)H * DH) + h * DH;
+                const int64_t op = (((int64_t)(b + vb) * Kq + f) * S + q_row[qi]) * ((int64_t)H * DH) + h * DH;
 #pragma unroll
                 for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
                         const int d0 = mt * 32 + 8 * rg + 4 * hi;
                         if (d0 < DH) {
-                            vec4 w;
+                            f32x4 w;
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) w[i] = (E)(o[vb][qi][mt][rg * 4 + i] * inv_l);
-                            *reinterpret_cast<u32x2*>(op + d0) = __builtin_bit_cast(u32x2, w);
+                            for (int i = 0; i < 4; ++i) w[i] = o[vb][qi][mt][rg * 4 + i] * inv_l;
+                            store_out4<E, vec4>(p.out, op + d0, w, p.out_f32);
                         }
                     }
             }
@@ -649,9 +665,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
 // Split form, second step: out = sum_seg O_seg 2^(sh_seg - M) / sum_seg l_seg 2^(sh_seg - M), M = max_seg sh_seg.
 // One thread per (bank, frame, head, query, 4 consecutive d).
 template <typename T>
-__global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ partials,
-                                                         typename T::elem* __restrict__ out, int Kq, int S, int H,
-                                                         int DH, int nseg) {
+__global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ partials, void* __restrict__ out,
+                                                         int Kq, int S, int H, int DH, int nseg, int out_f32) {
     typedef typename T::elem E;
     typedef typename T::vec4 vec4;
     const int PS = DH + 8, dq = DH >> 2;
@@ -676,11 +691,8 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
         const int h = (int)(t % H);
         t /= H;
         const int f = (int)(t % Kq), vbank = (int)(t / Kq);
-        vec4 w;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = (E)(num[i] * inv);
-        E* op = out + (((int64_t)(1 + vbank) * Kq + f) * S + q) * ((int64_t)H * DH) + h * DH + d0;
-        *reinterpret_cast<u32x2*>(op) = __builtin_bit_cast(u32x2, w);
+        store_out4<E, vec4>(out, (((int64_t)(1 + vbank) * Kq + f) * S + q) * ((int64_t)H * DH) + h * DH + d0, num * inv,
+                            out_f32);
     }
 }
 
@@ -951,7 +963,7 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
                 const float sh_old = m_run[qi];
                 const float sh_new = (first || mx > FOLD_T) ? (float)(E)(sh_old + mx) : sh_old;
                 const float delta = sh_new - sh_old;
-                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);   // O == 0 on the first tile
                 m_run[qi] = sh_new;
                 if (hi == SH_HI) qf[qi][SH_T][0] = (E)(-sh_new);
 #pragma unroll
@@ -1069,17 +1081,17 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
             l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32);
         const float inv_l = 1.0f / l_tot;
         if (q_ok[qi]) {
-            E* op = reinterpret_cast<E*>(p.out) + (((int64_t)b * Kq + f) * S + q_row[qi]) * ((int64_t)H * DH) + h * DH;
+            const int64_t op = (((int64_t)b * Kq + f) * S + q_row[qi]) * ((int64_t)H * DH) + h * DH;
 #pragma unroll
             for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     const int d0 = mt * 32 + 8 * rg + 4 * hi;
                     if (d0 < DH) {
-                        vec4 w;
+                        f32x4 w;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) w[i] = (E)(o[qi][mt][rg * 4 + i] * inv_l);
-                        *reinterpret_cast<u32x2*>(op + d0) = __builtin_bit_cast(u32x2, w);
+                        for (int i = 0; i < 4; ++i) w[i] = o[qi][mt][rg * 4 + i] * inv_l;
+                        store_out4<E, vec4>(p.out, op + d0, w, p.out_f32);
                     }
                 }
         }
@@ -1150,7 +1162,7 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
         const int64_t total = (int64_t)2 * p.Kq * p.H * p.S * (DH / 4);
         const int64_t blocks = (total + 255) / 256;
         hipLaunchKernelGGL(attn_merge_kernel<T>, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st,
-                           p.partials, reinterpret_cast<E*>(p.out), p.Kq, p.S, p.H, DH, p.nseg);
+                           p.partials, p.out, p.Kq, p.S, p.H, DH, p.nseg, p.out_f32);
         TF_LAUNCH_CHECK("tf_ext_attn_fwd(merge)");
         return 0;
     };
@@ -1241,7 +1253,7 @@ extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void
            TF_ERR_ALIGN, "tf_ext_attn_fwd: tensors not 16-byte aligned");
     TF_ARG(ws_bytes >= tf_ext_attn_workspace_bytes(K, S, H, Dh, dtype), TF_ERR_WORKSPACE,
            "tf_ext_attn_fwd: workspace %zu < %zu bytes", ws_bytes, tf_ext_attn_workspace_bytes(K, S, H, Dh, dtype));
-    AttnParams p;
+    AttnParams p{};
     p.q = q;
     p.k = k;
     p.vt = ws;
@@ -1257,13 +1269,14 @@ extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void
     p.nQT = (S + 127) / 128;
     p.inject = (inject & TF_ATTN_INJECT) ? 1 : 0;
     p.part = inject & (TF_ATTN_BANK_ONLY | TF_ATTN_SOURCE_ONLY);
+    p.exact_scale = (inject & TF_ATTN_EXACT_SCALE) ? 1 : 0;
+    p.out_f32 = (inject & TF_ATTN_OUT_F32) ? 1 : 0;
     p.nseg = split_plan(K, Kq, S, H, Dh, p.inject != 0, p.exact_scale != 0, p.part, !(inject & TF_ATTN_NO_SPLIT));
     p.partials = reinterpret_cast<float*>(
         reinterpret_cast<unsigned char*>(const_cast<float*>(p.knorm2)) +
         (((size_t)3 * H * K * (((S + 127) / 128) * 128 / 64) * sizeof(float) + 255) & ~(size_t)255));
     TF_ARG(p.part != (TF_ATTN_BANK_ONLY | TF_ATTN_SOURCE_ONLY), TF_ERR_SHAPE,
            "tf_ext_attn_fwd: TF_ATTN_BANK_ONLY and TF_ATTN_SOURCE_ONLY exclude each other");
-    p.exact_scale = (inject & TF_ATTN_EXACT_SCALE) ? 1 : 0;
     p.ld = ld;
     p.c = (float)((double)scale * 1.4426950408889634);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

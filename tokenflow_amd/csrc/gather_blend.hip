@@ -59,40 +59,62 @@ __device__ __forceinline__ void store8(T* p, const float (&f)[8]) {
 
 struct NoRes {};
 
+// Multi-chunk call (tf_nn_gather_blend_chunks): `n` frames are C chunks of nc frames; chunk j = frame / nc gathers
+// from keyframe slots kf0 + j and kf1 + j.  When the first chunk of the call is chunk 0 of the video it has ONE
+// keyframe (tokenflow_utils.py:331-333, 390): its rows are a1 + residual, rounded to the dtype the reference's
+// single-keyframe pass would produce (`single_dtype`: torch promotion of the cached output and hidden_states)
+// before they are widened to the call's output type -- so the call reproduces C separate calls bit for bit.
+struct GbChunks {
+    int nc;             // frames per chunk (0: not a multi-chunk call)
+    int first_single;
+    int single_dtype;   // TF_BF16 / TF_F16 / TF_F32
+};
+
 // MERGE: the indices come as the search's per-split partial results (tf_nn_gather_blend: no finalize launch
 // in between); every thread of a token merges them itself -- `splits` 8-byte reads, broadcast from cache.
-template <typename TIn, typename TRes, typename TOut, int P, bool MERGE>
+// CH: multi-chunk call (P == 2, MERGE).
+template <typename TIn, typename TRes, typename TOut, int P, bool MERGE, bool CH = false>
 __global__ __launch_bounds__(256) void gather_blend_kernel(const TIn* __restrict__ kf_out,
                                                            const int32_t* __restrict__ idx,
                                                            const NnPartial* __restrict__ part, int splits,
                                                            const float* __restrict__ w, const TRes* __restrict__ resid,
                                                            TOut* __restrict__ out, int K, int n, int S, int D, int kf0,
-                                                           int kf1) {
+                                                           int kf1, GbChunks ch) {
     const int ppr = D >> 3;  // pieces per row
     const int64_t nS = (int64_t)n * S;
     const int64_t total = nS * ppr;
     const int64_t branch_in = (int64_t)K * S * D;
     const int64_t branch_out = nS * D;
-    const TIn* src1 = kf_out + (int64_t)kf0 * S * D;
-    const TIn* src2 = kf_out + (int64_t)kf1 * S * D;
+    const int64_t frame_in = (int64_t)S * D;
+    const TIn* src1 = kf_out + (int64_t)kf0 * frame_in;
+    const TIn* src2 = kf_out + (int64_t)kf1 * frame_in;
     for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
         const int64_t t = g / ppr;
         const int c = (int)(g - t * ppr) * 8;
         const int i1 = MERGE ? nn_merge_partials(part + t, P * nS, splits) : idx[t];
         float w1 = 0.f, w2 = 0.f;
         int i2 = 0;
+        int frame = (int)(t / S);
+        int64_t coff = 0;        // CH: offset of this chunk's keyframe pair from (kf0, kf1)
+        bool single = false;     // CH: this token belongs to the one-keyframe chunk
+        if constexpr (CH) {
+            const int j = frame / ch.nc;
+            frame -= j * ch.nc;
+            coff = j * frame_in;
+            single = ch.first_single && j == 0;
+        }
         if constexpr (P == 2) {
-            i2 = MERGE ? nn_merge_partials(part + nS + t, P * nS, splits) : idx[nS + t];
-            w1 = w[(int)(t / S)];
+            if (!single) i2 = MERGE ? nn_merge_partials(part + nS + t, P * nS, splits) : idx[nS + t];
+            w1 = w[frame];
             w2 = __fsub_rn(1.0f, w1);
         }
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
             float a1[8], o[8];
-            load8(src1 + b * branch_in + (int64_t)i1 * D + c, a1);
-            if constexpr (P == 2) {
+            load8(src1 + coff + b * branch_in + (int64_t)i1 * D + c, a1);
+            if (P == 2 && !single) {
                 float a2[8];
-                load8(src2 + b * branch_in + (int64_t)i2 * D + c, a2);
+                load8(src2 + coff + b * branch_in + (int64_t)i2 * D + c, a2);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = __fadd_rn(__fmul_rn(w1, a1[i]), __fmul_rn(w2, a2[i]));
             } else {
@@ -105,6 +127,13 @@ __global__ __launch_bounds__(256) void gather_blend_kernel(const TIn* __restrict
                 load8(resid + off, h);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = __fadd_rn(o[i], h[i]);
+            }
+            if constexpr (CH) {
+                if (single && ch.single_dtype != TF_F32) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        o[i] = ch.single_dtype == TF_BF16 ? (float)(__bf16)o[i] : (float)(_Float16)o[i];
+                }
             }
             store8(out + off, o);
         }
@@ -130,6 +159,7 @@ struct GbArgs {
     void* out;
     int K, n, S, D, P, kf0, kf1;
     hipStream_t st;
+    GbChunks ch;
 };
 
 template <typename TIn, typename TRes, typename TOut>
@@ -139,9 +169,11 @@ void launch_gb(const GbArgs& a) {
     if (blocks > 256 * 16) blocks = 256 * 16;
     auto go = [&](auto kern, int kf1) {
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, a.st, (const TIn*)a.kf_out, a.idx, a.part,
-                           a.splits, a.w, (const TRes*)a.resid, (TOut*)a.out, a.K, a.n, a.S, a.D, a.kf0, kf1);
+                           a.splits, a.w, (const TRes*)a.resid, (TOut*)a.out, a.K, a.n, a.S, a.D, a.kf0, kf1, a.ch);
     };
-    if (a.part) {
+    if (a.ch.nc > 0) {
+        go(gather_blend_kernel<TIn, TRes, TOut, 2, true, true>, a.kf1);
+    } else if (a.part) {
         if (a.P == 2) go(gather_blend_kernel<TIn, TRes, TOut, 2, true>, a.kf1);
         else go(gather_blend_kernel<TIn, TRes, TOut, 1, true>, a.kf0);
     } else {
@@ -183,7 +215,8 @@ extern "C" int tf_gather_blend(const void* kf_out, const int32_t* idx, const flo
            TF_ERR_SHAPE, "tf_gather_blend: K=%d n=%d S=%d D=%d P=%d kf=(%d,%d)", K, n, S, D, P, kf0, kf1);
     TF_ARG(tf_aligned16(kf_out) && tf_aligned16(out) && tf_aligned16(resid), TF_ERR_ALIGN,
            "tf_gather_blend: tensors not 16-byte aligned");
-    GbArgs a{kf_out, idx, nullptr, 0, w, resid, out, K, n, S, D, P, kf0, kf1, reinterpret_cast<hipStream_t>(stream)};
+    GbArgs a{kf_out, idx, nullptr, 0, w, resid, out, K, n, S, D, P, kf0, kf1, reinterpret_cast<hipStream_t>(stream),
+             GbChunks{0, 0, 0}};
     switch (in_dtype) {
         case TF_BF16: dispatch_res<__bf16>(a, res_dtype, out_dtype); break;
         case TF_F16: dispatch_res<_Float16>(a, res_dtype, out_dtype); break;
@@ -225,13 +258,60 @@ extern "C" int tf_nn_gather_blend(const void* tgt, const void* piv, const float*
     int splits = 1;
     const int rc = tf_nn_search_partials(tgt, piv, inv_norm, part, n_tgt, S, D, P, kf0, kf1, search_dtype, st, &splits);
     if (rc) return rc;
-    GbArgs a{kf_out, nullptr, part, splits, w, resid, out, K, n, S, D, P, kf0, kf1, st};
+    GbArgs a{kf_out, nullptr, part, splits, w, resid, out, K, n, S, D, P, kf0, kf1, st, GbChunks{0, 0, 0}};
     switch (in_dtype) {
         case TF_BF16: dispatch_res<__bf16>(a, res_dtype, out_dtype); break;
         case TF_F16: dispatch_res<_Float16>(a, res_dtype, out_dtype); break;
         default: dispatch_res<float>(a, res_dtype, out_dtype); break;
     }
     TF_LAUNCH_CHECK("tf_nn_gather_blend");
+    return 0;
+}
+
+extern "C" size_t tf_nn_gather_blend_chunks_workspace_bytes(int64_t n_tgt_chunk, int S, int D, int C) {
+    if (n_tgt_chunk <= 0 || S <= 0 || D <= 0 || C <= 0) return 0;
+    const size_t b = tf_nn_partials_bytes(n_tgt_chunk, S, D, 2, C);
+    return b < 256 ? 256 : b;
+}
+
+extern "C" int tf_nn_gather_blend_chunks(const void* tgt, const void* piv, const float* inv_norm, const void* kf_out,
+                                         const float* w, const void* resid, void* out, int K, int n, int C, int S,
+                                         int D, int slot0, int first_single, int search_dtype, int in_dtype,
+                                         int res_dtype, int out_dtype, int single_dtype, void* ws, size_t ws_bytes,
+                                         void* stream) {
+    TF_ARG(tgt && piv && inv_norm && kf_out && out && ws && w, TF_ERR_NULL, "tf_nn_gather_blend_chunks: null pointer");
+    TF_ARG(search_dtype == TF_BF16 || search_dtype == TF_F16, TF_ERR_DTYPE,
+           "tf_nn_gather_blend_chunks: search dtype %d (bf16/f16 only)", search_dtype);
+    auto okdt = [](int d) { return d == TF_BF16 || d == TF_F16 || d == TF_F32; };
+    TF_ARG(okdt(in_dtype) && okdt(out_dtype) && okdt(single_dtype) && (!resid || okdt(res_dtype)), TF_ERR_DTYPE,
+           "tf_nn_gather_blend_chunks: dtypes in=%d res=%d out=%d single=%d", in_dtype, res_dtype, out_dtype,
+           single_dtype);
+    // chunk j reads keyframe slots slot0 + j and slot0 + j - 1 (the one-keyframe chunk only slot0)
+    TF_ARG(K > 0 && n > 0 && C > 0 && S > 0 && D > 0 && D % 8 == 0 && slot0 + C <= K &&
+               slot0 >= (first_single ? 0 : 1) && (C > 1 || !first_single),
+           TF_ERR_SHAPE, "tf_nn_gather_blend_chunks: K=%d n=%d C=%d S=%d D=%d slot0=%d first_single=%d", K, n, C, S, D,
+           slot0, first_single);
+    TF_ARG(tf_aligned16(tgt) && tf_aligned16(piv) && tf_aligned16(kf_out) && tf_aligned16(out) &&
+               tf_aligned16(resid) && tf_aligned16(ws),
+           TF_ERR_ALIGN, "tf_nn_gather_blend_chunks: tensors not 16-byte aligned");
+    const int64_t n_tgt = (int64_t)n * S;   // per chunk
+    TF_ARG(ws_bytes >= tf_nn_gather_blend_chunks_workspace_bytes(n_tgt, S, D, C), TF_ERR_WORKSPACE,
+           "tf_nn_gather_blend_chunks: workspace %zu < %zu bytes", ws_bytes,
+           tf_nn_gather_blend_chunks_workspace_bytes(n_tgt, S, D, C));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    NnPartial* part = reinterpret_cast<NnPartial*>(ws);
+    int splits = 1;
+    const int rc = tf_nn_search_partials(tgt, piv, inv_norm, part, n_tgt, S, D, 2, slot0, slot0 - 1, search_dtype, st,
+                                         &splits, C, first_single ? 1 : 0);
+    if (rc) return rc;
+    GbArgs a{kf_out, nullptr, part, splits, w, resid, out, K, n * C, S, D, 2, slot0, slot0 - 1, st,
+             GbChunks{n, first_single ? 1 : 0, single_dtype}};
+    switch (in_dtype) {
+        case TF_BF16: dispatch_res<__bf16>(a, res_dtype, out_dtype); break;
+        case TF_F16: dispatch_res<_Float16>(a, res_dtype, out_dtype); break;
+        default: dispatch_res<float>(a, res_dtype, out_dtype); break;
+    }
+    TF_LAUNCH_CHECK("tf_nn_gather_blend_chunks");
     return 0;
 }
 

@@ -23,6 +23,8 @@
 // Parallelism: grid = (target panels, P keyframes, SPLITS of the pivot range).  With SPLITS > 1
 // every workgroup writes its (best score, index) per target to scratch and nn_finalize_kernel
 // merges them in ascending split order (strict '>', so the first index still wins on ties).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "tf_common.h"
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
                                                         const float* __restrict__ inv_norm,
                                                         int32_t* __restrict__ idx_out,
                                                         NnPartial* __restrict__ part_out, int64_t n_tgt, int S,
-                                                        int D, int kf0, int kf1, int tiles_per_split) {
+                                                        int D, int kf0, int kf1, int tiles_per_split, NnChunks ch) {
     typedef typename T::vec8 vec8;
     constexpr int TN = 64 * WN;
     constexpr int PPR = BK / 8;              // 16-B pieces per chunk row
@@ -100,10 +102,15 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
     const int l31 = lane & 31;
 
     const int p = blockIdx.y;
-    const int kf = p == 0 ? kf0 : kf1;
+    // chunk of the video this target panel belongs to (0 in the single-chunk call): chunk j matches keyframe
+    // slots kf0 + j and kf1 + j; the first chunk of the video has ONE keyframe (tokenflow_utils.py:331-333)
+    const int chunk = blockIdx.x / ch.ppc;
+    if (p == 1 && chunk == 0 && ch.first_single) return;
+    const int kf = (p == 0 ? kf0 : kf1) + chunk;
     const typename T::elem* pv = piv + (int64_t)kf * S * D;
     const float* inv = inv_norm + (int64_t)kf * S;
-    const int64_t t0 = (int64_t)blockIdx.x * TN;
+    const int64_t t0 = chunk * ch.nS + (int64_t)(blockIdx.x - chunk * ch.ppc) * TN;
+    const int64_t t_end = (chunk + 1) * ch.nS;   // targets of this chunk: [chunk * nS, t_end)
 
     const int n_mt_all = (S + TM - 1) / TM;
     const int mt0 = blockIdx.z * tiles_per_split;           // this workgroup's slice of the pivot tiles
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
         for (int i = 0; i < NPB; ++i) {
             const int id = tid + 256 * i;
             const int r = id / PPR, pc = id % PPR;
-            const int64_t row = min(t0 + r, n_tgt - 1);
+            const int64_t row = min(t0 + r, t_end - 1);
             const int col = min(col0 + pc * 8, D - 8);
             rb[i] = ld16(tgt + row * D + col);
         }
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
         }
         i0 = i0 < S ? i0 : S - 1;  // a clamped duplicate of row S-1 maps back to S-1
         const int64_t t = t0 + tid;
-        if (t < n_tgt) {
+        if (t < t_end) {
             if (part_out)
                 part_out[((int64_t)blockIdx.z * gridDim.y + p) * n_tgt + t] = NnPartial{v0, i0};
             else
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(256, 3) void nn_search_rb_kernel(const typename T::
                                                            const float* __restrict__ inv_norm,
                                                            int32_t* __restrict__ idx_out,
                                                            NnPartial* __restrict__ part_out, int64_t n_tgt, int S,
-                                                           int kf0, int kf1, int tiles_per_split) {
+                                                           int kf0, int kf1, int tiles_per_split, NnChunks ch) {
     typedef typename T::elem E;
     typedef typename T::vec8 vec8;
     constexpr int D = 16 * DK;
@@ -304,10 +311,13 @@ __global__ __launch_bounds__(256, 3) void nn_search_rb_kernel(const typename T::
     const int hi = lane >> 5;
     const int l31 = lane & 31;
     const int p = blockIdx.y;
-    const int kf = p == 0 ? kf0 : kf1;
+    const int chunk = blockIdx.x / ch.ppc;       // see nn_search_kernel
+    if (p == 1 && chunk == 0 && ch.first_single) return;
+    const int kf = (p == 0 ? kf0 : kf1) + chunk;
     const E* pv = piv + (int64_t)kf * S * D;
     const float* inv = inv_norm + (int64_t)kf * S;
-    const int64_t t_row = (int64_t)blockIdx.x * 128 + wave * 32 + l31;
+    const int64_t t_end = (chunk + 1) * ch.nS;
+    const int64_t t_row = chunk * ch.nS + (int64_t)(blockIdx.x - chunk * ch.ppc) * 128 + wave * 32 + l31;
 
     const int n_mt_all = (S + TMR - 1) / TMR;
     const int mt0 = blockIdx.z * tiles_per_split;
@@ -315,7 +325,7 @@ __global__ __launch_bounds__(256, 3) void nn_search_rb_kernel(const typename T::
 
     vec8 fb[DK];
     {
-        const E* tp = tgt + (t_row < n_tgt ? t_row : n_tgt - 1) * D + 8 * hi;
+        const E* tp = tgt + (t_row < t_end ? t_row : t_end - 1) * D + 8 * hi;
 #pragma unroll
         for (int t = 0; t < DK; ++t) fb[t] = __builtin_bit_cast(vec8, ld16(tp + 16 * t));
     }
@@ -385,7 +395,7 @@ __global__ __launch_bounds__(256, 3) void nn_search_rb_kernel(const typename T::
         best_i = oi;
     }
     best_i = best_i < S ? best_i : S - 1;
-    if (hi == 0 && t_row < n_tgt) {
+    if (hi == 0 && t_row < t_end) {
         if (part_out)
             part_out[((int64_t)blockIdx.z * gridDim.y + p) * n_tgt + t_row] = NnPartial{best_v, best_i};
         else
@@ -414,19 +424,32 @@ struct NnPlan {
     int splits, tiles_per_split;
 };
 
-// splits of the pivot range so that the grid has >= ~4 workgroups per CU (1024) while every split keeps >= 1 tile
-static NnPlan nn_plan(int64_t n_tgt, int S, int D, int P) {
+// Grid target of the pivot-range split: workgroups the launch should have at least.  1024 = 4 per CU for one chunk.
+// A multi-chunk launch is C times larger; it keeps splitting up to TF_NN_MIN_WGS (environment, read once; default
+// 4096) so that the last round of workgroups is a small fraction of the launch.
+static int nn_min_wgs(int C) {
+    static const int env = [] {
+        const char* e = getenv("TF_NN_MIN_WGS");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 4096;
+    }();
+    return C > 1 ? env : 1024;
+}
+
+// splits of the pivot range so that the grid has >= nn_min_wgs workgroups while every split keeps >= 1 tile.
+// n_tgt = targets of ONE chunk, C = chunks in the launch (grid.x = C * panels).
+static NnPlan nn_plan(int64_t n_tgt, int S, int D, int P, int C = 1) {
     NnPlan pl;
     pl.rb = D == 320;
     // 128-target panels halve the pivot re-reads; they pay as soon as the grid still fills the GPU after
     // splitting the pivot range (measured at cfg2 level 1, 5120 targets x 2 keyframes: 34.6 vs 39.8 us)
-    pl.wide = !pl.rb && ((n_tgt + 127) / 128) * P >= 64;
+    pl.wide = !pl.rb && ((n_tgt + 127) / 128) * P * C >= 64;
     const int tn = pl.rb ? 128 : (pl.wide ? 128 : 64);
     const int tm = pl.rb ? 32 : TM;
     pl.panels = (n_tgt + tn - 1) / tn;
     const int n_tiles = (S + tm - 1) / tm;
     int splits = 1;
-    while (pl.panels * P * splits < 1024 && splits * 2 <= n_tiles) splits *= 2;
+    while (pl.panels * C * P * splits < nn_min_wgs(C) && splits * 2 <= n_tiles) splits *= 2;
     pl.tiles_per_split = (n_tiles + splits - 1) / splits;
     pl.splits = (n_tiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
     return pl;
@@ -439,50 +462,54 @@ static int finalize(const NnPartial* part, int32_t* idx, int64_t total, int spli
     return 0;
 }
 
+// n_tgt = targets per chunk; C chunks per launch (C = 1, first_single = 0: the plain single-chunk search).
+// Partial results / indices are laid out over all C * n_tgt targets.
 template <typename T, int WN, int BK>
 int launch_nn(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, NnPartial* ws, int64_t n_tgt,
-              int S, int D, int P, int kf0, int kf1, hipStream_t st, bool fin) {
+              int S, int D, int P, int kf0, int kf1, hipStream_t st, bool fin, int C, int first_single) {
     constexpr int TN = 64 * WN;
     const size_t lds = 2 * (TM + TN) * BK * 2 + 2 * TM * 4 + 2 * TN * 8;
-    const NnPlan pl = nn_plan(n_tgt, S, D, P);
+    const NnPlan pl = nn_plan(n_tgt, S, D, P, C);
     const int splits = pl.splits, tps = pl.tiles_per_split;
-    dim3 grid((unsigned)pl.panels, (unsigned)P, (unsigned)splits);
+    dim3 grid((unsigned)(pl.panels * C), (unsigned)P, (unsigned)splits);
     auto kern = nn_search_kernel<T, WN, BK>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const NnChunks ch{n_tgt, (int)pl.panels, first_single};
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, reinterpret_cast<const typename T::elem*>(tgt),
                        reinterpret_cast<const typename T::elem*>(piv), inv_norm, idx,
-                       (splits > 1 || !fin) ? ws : nullptr, n_tgt,
-                       S, D, kf0, kf1, tps);
+                       (splits > 1 || !fin) ? ws : nullptr, n_tgt * C, S, D, kf0, kf1, tps, ch);
     TF_LAUNCH_CHECK("tf_nn_search");
-    return (fin && splits > 1) ? finalize(ws, idx, n_tgt * P, splits, st) : 0;
+    return (fin && splits > 1) ? finalize(ws, idx, n_tgt * C * P, splits, st) : 0;
 }
 
 template <typename T, int DK>
 int launch_nn_rb(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, NnPartial* ws, int64_t n_tgt,
-                 int S, int P, int kf0, int kf1, hipStream_t st, bool fin) {
+                 int S, int P, int kf0, int kf1, hipStream_t st, bool fin, int C, int first_single) {
     constexpr int D = 16 * DK;
     const size_t lds = 2 * 32 * (D + 8) * 2 + 2 * 32 * 4;
-    const NnPlan pl = nn_plan(n_tgt, S, D, P);
+    const NnPlan pl = nn_plan(n_tgt, S, D, P, C);
     const int splits = pl.splits, tps = pl.tiles_per_split;
-    dim3 grid((unsigned)pl.panels, (unsigned)P, (unsigned)splits);
+    dim3 grid((unsigned)(pl.panels * C), (unsigned)P, (unsigned)splits);
+    const NnChunks ch{n_tgt, (int)pl.panels, first_single};
     hipLaunchKernelGGL((nn_search_rb_kernel<T, DK>), grid, dim3(256), lds, st,
                        reinterpret_cast<const typename T::elem*>(tgt), reinterpret_cast<const typename T::elem*>(piv),
-                       inv_norm, idx, (splits > 1 || !fin) ? ws : nullptr, n_tgt, S, kf0, kf1, tps);
+                       inv_norm, idx, (splits > 1 || !fin) ? ws : nullptr, n_tgt * C, S, kf0, kf1, tps, ch);
     TF_LAUNCH_CHECK("tf_nn_search");
-    return (fin && splits > 1) ? finalize(ws, idx, n_tgt * P, splits, st) : 0;
+    return (fin && splits > 1) ? finalize(ws, idx, n_tgt * C * P, splits, st) : 0;
 }
 
 template <typename T>
 int dispatch_nn(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, NnPartial* ws, int64_t n_tgt,
-                int S, int D, int P, int kf0, int kf1, hipStream_t st, bool fin) {
-    const NnPlan pl = nn_plan(n_tgt, S, D, P);
-    if (pl.rb) return launch_nn_rb<T, 20>(tgt, piv, inv_norm, idx, ws, n_tgt, S, P, kf0, kf1, st, fin);
+                int S, int D, int P, int kf0, int kf1, hipStream_t st, bool fin, int C = 1, int first_single = 0) {
+    const NnPlan pl = nn_plan(n_tgt, S, D, P, C);
+    if (pl.rb) return launch_nn_rb<T, 20>(tgt, piv, inv_norm, idx, ws, n_tgt, S, P, kf0, kf1, st, fin, C, first_single);
     // 128-target panels for all but the small target sets (nn_plan), else 64-target panels
-    if (pl.wide) return launch_nn<T, 2, 64>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin);
+    if (pl.wide)
+        return launch_nn<T, 2, 64>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin, C, first_single);
     // few workgroups and a long contraction: latency-bound per iteration -> 128-wide D chunks
-    if (pl.panels * P * pl.splits <= 512 && D >= 512)
-        return launch_nn<T, 1, 128>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin);
-    return launch_nn<T, 1, 64>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin);
+    if (pl.panels * C * P * pl.splits <= 512 && D >= 512)
+        return launch_nn<T, 1, 128>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin, C, first_single);
+    return launch_nn<T, 1, 64>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin, C, first_single);
 }
 
 }  // namespace
@@ -530,13 +557,14 @@ extern "C" int tf_nn_search(const void* tgt, const void* piv, const float* inv_n
 }
 
 int tf_nn_search_partials(const void* tgt, const void* piv, const float* inv_norm, NnPartial* part, int64_t n_tgt,
-                          int S, int D, int P, int kf0, int kf1, int dtype, hipStream_t st, int* splits) {
-    *splits = nn_plan(n_tgt, S, D, P).splits;
+                          int S, int D, int P, int kf0, int kf1, int dtype, hipStream_t st, int* splits, int C,
+                          int first_single) {
+    *splits = nn_plan(n_tgt, S, D, P, C).splits;
     return dtype == TF_BF16
-               ? dispatch_nn<BF16>(tgt, piv, inv_norm, nullptr, part, n_tgt, S, D, P, kf0, kf1, st, false)
-               : dispatch_nn<F16>(tgt, piv, inv_norm, nullptr, part, n_tgt, S, D, P, kf0, kf1, st, false);
+               ? dispatch_nn<BF16>(tgt, piv, inv_norm, nullptr, part, n_tgt, S, D, P, kf0, kf1, st, false, C, first_single)
+               : dispatch_nn<F16>(tgt, piv, inv_norm, nullptr, part, n_tgt, S, D, P, kf0, kf1, st, false, C, first_single);
 }
 
-size_t tf_nn_partials_bytes(int64_t n_tgt, int S, int D, int P) {
-    return (size_t)nn_plan(n_tgt, S, D, P).splits * P * n_tgt * sizeof(NnPartial);
+size_t tf_nn_partials_bytes(int64_t n_tgt, int S, int D, int P, int C) {
+    return (size_t)nn_plan(n_tgt, S, D, P, C).splits * P * n_tgt * C * sizeof(NnPartial);
 }

@@ -60,10 +60,19 @@ __device__ __forceinline__ int nn_merge_partials(const NnPartial* part, int64_t 
     }
     return b.i;
 }
-// Search only (no finalize launch): partial results [splits][P][n_tgt] into `part`; arguments already validated.
+// A launch over C consecutive chunks of the video (C = 1: the reference's one chunk per call): target panel ->
+// chunk j = panel / ppc, whose nS targets are matched against keyframe slots kf0 + j and kf1 + j.
+struct NnChunks {
+    int64_t nS;        // targets per chunk (n frames * S tokens)
+    int ppc;           // target panels per chunk
+    int first_single;  // chunk 0 of the launch is chunk 0 of the video: ONE keyframe (tokenflow_utils.py:331-333)
+};
+// Search only (no finalize launch): partial results [splits][P][C * n_tgt] into `part`; arguments already validated.
+// n_tgt = targets per chunk.
 int tf_nn_search_partials(const void* tgt, const void* piv, const float* inv_norm, NnPartial* part, int64_t n_tgt,
-                          int S, int D, int P, int kf0, int kf1, int dtype, hipStream_t st, int* splits);
-size_t tf_nn_partials_bytes(int64_t n_tgt, int S, int D, int P);
+                          int S, int D, int P, int kf0, int kf1, int dtype, hipStream_t st, int* splits, int C = 1,
+                          int first_single = 0);
+size_t tf_nn_partials_bytes(int64_t n_tgt, int S, int D, int P, int C = 1);
 
 // ---- host-side error plumbing ------------------------------------------------
 void tf_set_error(const char* fmt, ...);

@@ -24,7 +24,10 @@ What differs from the reference is only *how* the tensors are computed:
 There is no CPU / eager fallback: the ops raise on CPU tensors or when the HIP library is
 missing.
 """
+import collections
+import logging
 import os
+import sys
 from typing import Type
 
 import torch
@@ -99,11 +102,14 @@ def register_time(model, t):
     setattr(tb.attn2, "t", t)
 
 
-_latents_cache = {}
+_latents_cache = collections.OrderedDict()
+_LATENTS_CACHE_ENTRIES = 2      # the current timestep's file (+ one): the driver loads the SAME file C+1 times per step
 
 
 def load_source_latents_t(t, latents_path):
-    """tokenflow_utils.py:43-47, with an in-memory cache keyed by (path, mtime)."""
+    """tokenflow_utils.py:43-47.  The reference re-reads the file on each of the C+1 calls of a denoising step
+    (run_tokenflow_pnp.py:198,221); here the most recent files are kept, keyed by (path, mtime) -- a bounded
+    LRU, so nothing but the current timestep's latents stays resident."""
     latents_t_path = os.path.join(latents_path, f"noisy_latents_{t}.pt")
     assert os.path.exists(latents_t_path), f"Missing latents at t {t} path {latents_t_path}"
     key = (latents_t_path, os.path.getmtime(latents_t_path))
@@ -111,6 +117,10 @@ def load_source_latents_t(t, latents_path):
     if hit is None:
         hit = torch.load(latents_t_path)
         _latents_cache[key] = hit
+        while len(_latents_cache) > _LATENTS_CACHE_ENTRIES:
+            _latents_cache.popitem(last=False)
+    else:
+        _latents_cache.move_to_end(key)
     return hit
 
 
@@ -187,6 +197,66 @@ def register_conv_injection(model, injection_schedule):
 
 
 # --------------------------------------------------------------------------- extended attention
+_announced = False
+
+
+def _announce():
+    """One line on stderr the first time a hook is installed: a run that silently picked up the reference's own
+    `tokenflow_utils.py` (the script directory precedes PYTHONPATH on sys.path) never prints it."""
+    global _announced
+    if _announced:
+        return
+    _announced = True
+    from . import _lib
+    lib = _lib.load()                    # fails loudly here, at installation time, if the library is missing
+    msg = f"[tokenflow_amd] MI355X HIP hook path active ({_lib.LIB_PATH}, ABI v{lib.tf_abi_version()})"
+    logging.getLogger("tokenflow_amd").info(msg)
+    if os.environ.get("TOKENFLOW_QUIET", "0") in ("", "0"):
+        print(msg, file=sys.stderr, flush=True)
+
+
+def _fused_qkv(attn, x: torch.Tensor):
+    """q, k, v of a self-attention as column slabs of ONE projection `x @ [Wq; Wk; Wv]^T` (row f2 of SURVEY.md
+    section 8; tokenflow_utils.py:120-122 issues three Linear calls): one GEMM, one output [3K, S, 3D] that the
+    attention kernel reads in place through its row stride, no per-tensor dtype casts.  The concatenated weight is
+    cached on the module, keyed by the three weights' storage, version counter and the compute dtype, so an
+    optimizer step, a `.to()` or a LoRA merge rebuilds it.  Returns None when the three projections are not
+    plain bias-compatible `nn.Linear` layers over the same input (then the caller issues them one by one).
+    Returns the [..., 3D] projection output; q, k, v are its three D-wide column slabs."""
+    lq, lk, lv = attn.to_q, attn.to_k, attn.to_v
+    Linear = torch.nn.Linear
+    if not (type(lq) is Linear and type(lk) is Linear and type(lv) is Linear and x.is_cuda):
+        return None
+    wq, wk, wv = lq.weight, lk.weight, lv.weight
+    if not (wq.shape == wk.shape == wv.shape and wq.dtype == wk.dtype == wv.dtype and wq.shape[1] == x.shape[-1]):
+        return None
+    biases = (lq.bias, lk.bias, lv.bias)
+    if any(b is None for b in biases) != all(b is None for b in biases):
+        return None
+    if torch.is_autocast_enabled("cuda"):
+        cdt = torch.get_autocast_dtype("cuda")
+    else:
+        cdt = x.dtype if x.dtype == wq.dtype else None
+    if cdt is None:
+        return None
+    key = (cdt, wq.data_ptr(), wk.data_ptr(), wv.data_ptr(), wq._version, wk._version, wv._version,
+           None if biases[0] is None else tuple((b.data_ptr(), b._version) for b in biases))
+    cached = attn.__dict__.get("_tf_qkv_cache")
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            wcat = torch.cat([wq, wk, wv], dim=0).to(cdt).contiguous()
+            bcat = None if biases[0] is None else torch.cat(list(biases), dim=0).to(cdt).contiguous()
+        cached = (key, wcat, bcat)
+        attn.__dict__["_tf_qkv_cache"] = cached
+    _, wcat, bcat = cached
+    with torch.autocast("cuda", enabled=False):
+        qkv = torch.nn.functional.linear(x.to(cdt), wcat, bcat)
+    return qkv
+
+
+FUSE_QKV = os.environ.get("TOKENFLOW_FUSED_QKV", "1") not in ("", "0")
+
+
 def _make_sa_forward(self, pnp: bool):
     to_out = self.to_out
     if type(to_out) is torch.nn.modules.container.ModuleList:
@@ -194,14 +264,24 @@ def _make_sa_forward(self, pnp: bool):
 
     def forward(x, encoder_hidden_states=None, attention_mask=None):
         is_cross = encoder_hidden_states is not None
-        encoder_hidden_states = encoder_hidden_states if is_cross else x
-        q = self.to_q(x)
-        k = self.to_k(encoder_hidden_states)
-        v = self.to_v(encoder_hidden_states)
+        qkv = _fused_qkv(self, x) if (FUSE_QKV and not is_cross) else None
+        if qkv is not None:
+            proj_dtype = qkv.dtype
+            cdt = ops.compute_dtype(qkv)
+            if proj_dtype != cdt:        # fp32 model without autocast: ONE cast of the fused output
+                qkv = qkv.to(cdt)
+            D = qkv.shape[-1] // 3
+            q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]     # column slabs, row stride 3D
+        else:
+            encoder_hidden_states = encoder_hidden_states if is_cross else x
+            q, k, v = self.to_q(x), self.to_k(encoder_hidden_states), self.to_v(encoder_hidden_states)
+            proj_dtype = q.dtype
+            cdt = ops.compute_dtype(q)
+            if proj_dtype != cdt:
+                q, k, v = q.to(cdt), k.to(cdt), v.to(cdt)
         inject = pnp and _injecting(self)
-        cdt = ops.compute_dtype(q)
-        out = ops.ext_attn(q.to(cdt), k.to(cdt), v.to(cdt), self.heads, self.scale, inject)
-        return to_out(out.to(q.dtype))
+        out = ops.ext_attn(q, k, v, self.heads, self.scale, inject)
+        return to_out(out if out.dtype == proj_dtype else out.to(proj_dtype))
 
     return forward
 
@@ -210,6 +290,7 @@ def register_extended_attention_pnp(model, injection_schedule):
     """tokenflow_utils.py:106-214: every BasicTransformerBlock.attn1 gets the extended
     attention with an empty schedule (203-206); the 8 decoder blocks
     up_blocks[1].attentions[1,2], up_blocks[2,3].attentions[0..2] get the real one (208-214)."""
+    _announce()
     for _, module in model.unet.named_modules():
         if isinstance_str(module, "BasicTransformerBlock"):
             module.attn1.forward = _make_sa_forward(module.attn1, pnp=True)
@@ -223,6 +304,7 @@ def register_extended_attention_pnp(model, injection_schedule):
 
 def register_extended_attention(model):
     """tokenflow_utils.py:216-294 (SDEdit driver): extended attention, never injects."""
+    _announce()
     for _, module in model.unet.named_modules():
         if isinstance_str(module, "BasicTransformerBlock"):
             module.attn1.forward = _make_sa_forward(module.attn1, pnp=False)
@@ -275,6 +357,19 @@ def _block_norm(mod: torch.nn.Module, x: torch.Tensor, want_inv_norm: bool = Fal
     return ops.layer_norm(x, mod.weight, mod.bias, mod.eps, dt, want_inv_norm)
 
 
+def _chunk_run(batch_idx):
+    """(first chunk, number of chunks) of a `batch_idx` state.  The reference sets an int (one chunk of
+    n = batch_size frames per UNet pass, run_tokenflow_pnp.py:228-231).  Extension for large-memory GPUs: a
+    `range` / list of CONSECUTIVE chunk indices means the pass carries all those chunks, frames chunk-major
+    inside every branch -- one UNet pass over the whole video instead of C passes."""
+    if isinstance(batch_idx, (range, list, tuple)):
+        ids = [int(i) for i in batch_idx]
+        if not ids or any(b - a != 1 for a, b in zip(ids, ids[1:])):
+            raise ValueError(f"batch_idx {batch_idx!r}: need a non-empty run of consecutive chunk indices")
+        return ids[0], len(ids)
+    return int(batch_idx), 1
+
+
 def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[torch.nn.Module]:
     """tokenflow_utils.py:296-429."""
 
@@ -288,6 +383,7 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
             hidden_states = hidden_states.view(3, n_frames, sequence_length, dim)
 
             norm_inv = None
+            gate_msa = None
             if self.use_ada_layer_norm:
                 norm_hidden_states = self.norm1(hidden_states, timestep)
             elif self.use_ada_layer_norm_zero:
@@ -316,35 +412,52 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
                 hidden_states = hidden_states.reshape(batch_size, sequence_length, dim)
                 hidden_states = attn_output + hidden_states
             else:
+                c0, n_chunks = _chunk_run(self.batch_idx)
+                if n_frames % n_chunks:
+                    raise ValueError(f"{n_frames} frames per branch do not split into {n_chunks} chunks")
+                n = n_frames // n_chunks
+                kf = self.kf_attn_output
+                K = kf.shape[0] // 3
                 if self.use_ada_layer_norm_zero:
-                    raise NotImplementedError(
-                        "TokenFlow propagation with AdaLayerNormZero blocks is not supported on the HIP path "
-                        "(Stable Diffusion UNets do not use it)")
-                # 329-348: nearest neighbours of the SOURCE branch among keyframe i (and i-1)
-                batch_idxs = [self.batch_idx]
-                if self.batch_idx > 0:
-                    batch_idxs.append(self.batch_idx - 1)
+                    # 362-366: the reference gates the SELECTED keyframe outputs before the gather:
+                    # `attn_output = gate_msa.unsqueeze(1) * kf_attn_output.view(3,K,S,D)[:, batch_idxs]`.  Same
+                    # torch expression here (same broadcasting, same promotion) on the keyframes this pass reads;
+                    # the gated copy becomes the gather source, re-indexed from 0.
+                    lo = max(c0 - 1, 0)
+                    sel = kf.view(3, K, sequence_length, dim)[:, lo:c0 + n_chunks]
+                    kf = (gate_msa.unsqueeze(1) * sel).reshape(-1, sequence_length, dim)
+                    self.attn_output = kf.view(3, -1, sequence_length, dim)
+                    kf_base, K = lo, kf.shape[0] // 3
+                else:
+                    kf_base = 0
+                # 329-348: nearest neighbours of the SOURCE branch among keyframe c (and c-1), per chunk
                 tgt = norm_hidden_states[0].reshape(n_frames * sequence_length, dim).to(self._tf_pivots.dtype)
                 # 361-397: gather (same indices for the 3 branches), blend, residual -- fused with the search.
                 # dtype follows torch promotion in the reference: the blend is fp32 (w1 is fp32, 385-388),
                 # chunk 0 keeps the cached dtype (390); then `attn_output + hidden_states` (397).
-                kf = self.kf_attn_output
-                blend_dtype = torch.float32 if len(batch_idxs) == 2 else kf.dtype
+                two = c0 + n_chunks - 1 > 0                      # some chunk blends two keyframes
+                blend_dtype = torch.float32 if two else kf.dtype
                 out_dtype = torch.promote_types(blend_dtype, hidden_states.dtype)
-                w = _blend_weights(n_frames, kf.device) if len(batch_idxs) == 2 else None
-                hidden_states = ops.propagate(tgt, self._tf_pivots, self._tf_pivot_inv_norm, batch_idxs, kf, w,
-                                              n_frames, hidden_states.reshape(batch_size, sequence_length, dim),
-                                              out_dtype)
+                w = _blend_weights(n, kf.device) if two else None
+                resid = hidden_states.reshape(batch_size, sequence_length, dim)
+                piv, inv = self._tf_pivots, self._tf_pivot_inv_norm
+                if kf_base:      # gated copy holds keyframes kf_base.. only: search the same window of the pivots
+                    piv, inv = piv[kf_base:kf_base + K], inv[kf_base:kf_base + K]
+                if n_chunks == 1:
+                    ids = [c0 - kf_base] if c0 == 0 else [c0 - kf_base, c0 - 1 - kf_base]
+                    hidden_states = ops.propagate(tgt, piv, inv, ids, kf, w, n, resid, out_dtype)
+                else:
+                    hidden_states = ops.propagate_chunks(tgt, piv, inv, kf, w, n, n_chunks, c0 - kf_base, c0 == 0,
+                                                         resid, out_dtype)
 
             if self.attn2 is not None:
                 norm_hidden_states = (
-                    self.norm2(hidden_states, timestep) if self.use_ada_layer_norm
-                    else _block_norm(self.norm2, hidden_states)[0])
+                    self.norm2(hidden_states, timestep) if self.use_ada_layer_norm else self.norm2(hidden_states))
                 attn_output = self.attn2(norm_hidden_states, encoder_hidden_states=encoder_hidden_states,
                                          attention_mask=encoder_attention_mask, **cross_attention_kwargs)
                 hidden_states = attn_output + hidden_states
 
-            norm_hidden_states = _block_norm(self.norm3, hidden_states)[0]
+            norm_hidden_states = self.norm3(hidden_states)
             if self.use_ada_layer_norm_zero:
                 norm_hidden_states = norm_hidden_states * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
             ff_output = self.ff(norm_hidden_states)
@@ -357,6 +470,7 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
 
 def set_tokenflow(model: torch.nn.Module):
     """tokenflow_utils.py:432-448: class-swap every BasicTransformerBlock in place."""
+    _announce()
     for _, module in model.named_modules():
         if isinstance_str(module, "BasicTransformerBlock"):
             module.__class__ = make_tokenflow_attention_block(module.__class__)

@@ -10,15 +10,33 @@ from . import _lib
 _DT = {torch.bfloat16: _lib.TF_BF16, torch.float16: _lib.TF_F16, torch.float32: _lib.TF_F32}
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
-
-
 def _need_gpu(*ts):
+    """All tensors on ONE GPU (no CPU fallback, no cross-device launches)."""
+    dev = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise _lib.TokenflowHipError(
                 "tokenflow_amd ops run on MI355X only: got a CPU tensor (there is no CPU fallback)")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise _lib.TokenflowHipError(f"tokenflow_amd ops: tensors on different devices ({dev} and {t.device})")
+    return dev
+
+
+def _launch(dev, what: str, fn, *args):
+    """Call a C-ABI entry point whose last argument is the stream: the launch goes to the CURRENT stream OF THE
+    TENSORS' DEVICE, with that device made current for the duration of the call when it is not already (a kernel
+    enqueued on another device's stream with foreign pointers faults or corrupts memory)."""
+    if dev.index != torch.cuda.current_device():
+        with torch.cuda.device(dev):
+            rc = fn(*args, torch.cuda.current_stream(dev).cuda_stream)
+    else:
+        rc = fn(*args, torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        _lib.check(rc, what)
 
 
 def compute_dtype(t: torch.Tensor) -> torch.dtype:
@@ -31,6 +49,10 @@ _attn_ws_bytes = {}   # (K, S, H, Dh, dtype) -> scratch bytes of tf_ext_attn_fwd
 
 
 def _workspace(nbytes: int, device, tag: str = "attn") -> torch.Tensor:
+    """Scratch for one launch, cached per (purpose, device, stream).  While a HIP graph is being captured the
+    buffer comes from the graph's private pool and must live and die with that graph: never cached."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
     key = (tag, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
@@ -49,13 +71,16 @@ NO_SPLIT = os.environ.get("TOKENFLOW_ATTN_NO_SPLIT", "0") not in ("", "0")
 
 def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float,
              inject: bool, out: Optional[torch.Tensor] = None, q_frame0: int = 0,
-             exact_scale: Optional[bool] = None, part: str = "all") -> torch.Tensor:
+             exact_scale: Optional[bool] = None, part: str = "all",
+             out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """Extended attention core (tokenflow_utils.py:124-197).  k,v: [3K,S,D] bf16/f16 (the bank),
     q: [3Kq,S,D] = the queries of keyframes q_frame0..q_frame0+Kq-1 (Kq = K on one GPU); last dim
-    contiguous, equal token stride.  Returns [3Kq,S,D] in the same dtype.
+    contiguous, equal token stride (q, k, v may be column slabs of one fused projection output).
+    Returns [3Kq,S,D] in the same dtype, or in fp32 with out_dtype=torch.float32 (the normalised fp32
+    accumulator, no 16-bit output rounding).
     part = "bank": only the uncond/cond branches are computed (the source slabs of v and out, and those
     of q, k that the call does not read, are never touched); part = "source": only the source branch."""
-    _need_gpu(q, k, v)
+    dev = _need_gpu(q, k, v, out)
     lib = _lib.load()
     B, S, D = k.shape
     Bq = q.shape[0]
@@ -75,9 +100,17 @@ def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scal
     if k.stride(1) != ld or v.stride(1) != ld:
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         ld = D
+    if out_dtype is None:
+        out_dtype = out.dtype if out is not None else q.dtype
+    if out_dtype not in (q.dtype, torch.float32):
+        raise TypeError(f"ext_attn: out_dtype {out_dtype} (the input dtype or float32)")
     if out is None:
-        out = torch.empty(Bq, S, D, dtype=q.dtype, device=q.device)
+        out = torch.empty(Bq, S, D, dtype=out_dtype, device=q.device)
+    elif out.dtype != out_dtype or not out.is_contiguous() or out.shape != (Bq, S, D):
+        raise ValueError("ext_attn: `out` must be a contiguous [3Kq,S,D] tensor of out_dtype")
     flags = (1 if inject else 0) | (2 if (EXACT_SCALE if exact_scale is None else exact_scale) else 0)
+    if out_dtype == torch.float32:
+        flags |= _lib.TF_ATTN_OUT_F32
     flags |= {"all": 0, "bank": _lib.TF_ATTN_BANK_ONLY, "source": _lib.TF_ATTN_SOURCE_ONLY}[part]
     if NO_SPLIT:
         flags |= _lib.TF_ATTN_NO_SPLIT
@@ -86,30 +119,27 @@ def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scal
     if nbytes is None:
         nbytes = _attn_ws_bytes[key] = lib.tf_ext_attn_workspace_bytes(K, S, heads, dh, dt)
     ws = _workspace(nbytes, q.device)
-    _lib.check(lib.tf_ext_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), K, Kq, int(q_frame0),
-                                   S, heads, dh,
-                                   ld, float(scale), flags, dt, ws.data_ptr(), ws.numel(), _stream()),
-               "tf_ext_attn_fwd")
+    _launch(dev, "tf_ext_attn_fwd", lib.tf_ext_attn_fwd, q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+            K, Kq, int(q_frame0), S, heads, dh, ld, float(scale), flags, dt, ws.data_ptr(), ws.numel())
     return out
 
 
 def pivot_inv_norm(piv: torch.Tensor) -> torch.Tensor:
     """1/||row|| for pivots [..., D] (bf16/f16, contiguous) -> fp32 [...]."""
-    _need_gpu(piv)
+    dev = _need_gpu(piv)
     lib = _lib.load()
     piv = piv.contiguous()
     D = piv.shape[-1]
     rows = piv.numel() // D
     out = torch.empty(piv.shape[:-1], dtype=torch.float32, device=piv.device)
-    _lib.check(lib.tf_pivot_inv_norm(piv.data_ptr(), out.data_ptr(), rows, D, _DT[piv.dtype], _stream()),
-               "tf_pivot_inv_norm")
+    _launch(dev, "tf_pivot_inv_norm", lib.tf_pivot_inv_norm, piv.data_ptr(), out.data_ptr(), rows, D, _DT[piv.dtype])
     return out
 
 
 def nn_search(tgt: torch.Tensor, piv: torch.Tensor, inv_norm: torch.Tensor, kf_ids: Sequence[int]) -> torch.Tensor:
     """tgt [n*S, D], piv [K, S, D] (same 16-bit dtype), inv_norm fp32 [K, S]; kf_ids = 1 or 2 keyframe
     indices in the reference's order [i, i-1] (tokenflow_utils.py:331-333).  Returns int32 [P, n*S]."""
-    _need_gpu(tgt, piv, inv_norm)
+    dev = _need_gpu(tgt, piv, inv_norm)
     lib = _lib.load()
     tgt, piv = tgt.contiguous(), piv.contiguous()
     K, S, D = piv.shape
@@ -119,9 +149,8 @@ def nn_search(tgt: torch.Tensor, piv: torch.Tensor, inv_norm: torch.Tensor, kf_i
         raise ValueError("nn_search: bad arguments")
     idx = torch.empty(P, n_tgt, dtype=torch.int32, device=tgt.device)
     ws = _workspace(lib.tf_nn_search_workspace_bytes(n_tgt, S, D, P), tgt.device, "nn")
-    _lib.check(lib.tf_nn_search(tgt.data_ptr(), piv.data_ptr(), inv_norm.data_ptr(), idx.data_ptr(), n_tgt, S, D, P,
-                                int(kf_ids[0]), int(kf_ids[1]) if P == 2 else 0, _DT[tgt.dtype],
-                                ws.data_ptr(), ws.numel(), _stream()), "tf_nn_search")
+    _launch(dev, "tf_nn_search", lib.tf_nn_search, tgt.data_ptr(), piv.data_ptr(), inv_norm.data_ptr(), idx.data_ptr(),
+            n_tgt, S, D, P, int(kf_ids[0]), int(kf_ids[1]) if P == 2 else 0, _DT[tgt.dtype], ws.data_ptr(), ws.numel())
     return idx
 
 
@@ -129,7 +158,7 @@ def gather_blend(kf_out: torch.Tensor, idx: torch.Tensor, w: Optional[torch.Tens
                  n: int, residual: Optional[torch.Tensor], out_dtype: torch.dtype) -> torch.Tensor:
     """kf_out [3K,S,D]; idx int32 [P, n*S]; w fp32 [n] (P == 2); residual [3n,S,D] or None.
     Returns [3n,S,D] of out_dtype (tokenflow_utils.py:362-397)."""
-    _need_gpu(kf_out, idx, w, residual)
+    dev = _need_gpu(kf_out, idx, w, residual)
     lib = _lib.load()
     kf_out = kf_out.contiguous()
     BK, S, D = kf_out.shape
@@ -138,11 +167,10 @@ def gather_blend(kf_out: torch.Tensor, idx: torch.Tensor, w: Optional[torch.Tens
     if residual is not None:
         residual = residual.contiguous()
     out = torch.empty(3 * n, S, D, dtype=out_dtype, device=kf_out.device)
-    _lib.check(lib.tf_gather_blend(kf_out.data_ptr(), idx.data_ptr(), w.data_ptr() if w is not None else 0,
-                                   residual.data_ptr() if residual is not None else 0, out.data_ptr(),
-                                   K, n, S, D, P, int(kf_ids[0]), int(kf_ids[1]) if P == 2 else 0,
-                                   _DT[kf_out.dtype], _DT[residual.dtype] if residual is not None else 0,
-                                   _DT[out_dtype], _stream()), "tf_gather_blend")
+    _launch(dev, "tf_gather_blend", lib.tf_gather_blend, kf_out.data_ptr(), idx.data_ptr(),
+            w.data_ptr() if w is not None else 0, residual.data_ptr() if residual is not None else 0, out.data_ptr(),
+            K, n, S, D, P, int(kf_ids[0]), int(kf_ids[1]) if P == 2 else 0, _DT[kf_out.dtype],
+            _DT[residual.dtype] if residual is not None else 0, _DT[out_dtype])
     return out
 
 
@@ -150,7 +178,7 @@ def layer_norm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[t
                out_dtype: torch.dtype, want_inv_norm: bool = False):
     """LayerNorm over the last dim of x [..., D] (fp32 statistics, one rounding to out_dtype) and, on request,
     1/||row||_2 of the rounded output rows (fp32 [...]).  Returns (out, inv_norm or None)."""
-    _need_gpu(x, weight, bias)
+    dev = _need_gpu(x, weight, bias)
     lib = _lib.load()
     x = x.contiguous()
     D = x.shape[-1]
@@ -164,10 +192,9 @@ def layer_norm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[t
     bias = bias.contiguous() if bias is not None else None
     out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     inv = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device) if want_inv_norm else None
-    _lib.check(lib.tf_layer_norm(x.data_ptr(), weight.data_ptr() if weight is not None else 0,
-                                 bias.data_ptr() if bias is not None else 0, out.data_ptr(),
-                                 inv.data_ptr() if inv is not None else 0, rows, D, float(eps), _DT[x.dtype],
-                                 _DT[wt.dtype] if wt is not None else 0, _DT[out_dtype], _stream()), "tf_layer_norm")
+    _launch(dev, "tf_layer_norm", lib.tf_layer_norm, x.data_ptr(), weight.data_ptr() if weight is not None else 0,
+            bias.data_ptr() if bias is not None else 0, out.data_ptr(), inv.data_ptr() if inv is not None else 0,
+            rows, D, float(eps), _DT[x.dtype], _DT[wt.dtype] if wt is not None else 0, _DT[out_dtype])
     return out, inv
 
 
@@ -176,7 +203,7 @@ def propagate(tgt: torch.Tensor, piv: torch.Tensor, inv_norm: torch.Tensor, kf_i
               out_dtype: torch.dtype) -> torch.Tensor:
     """nn_search + gather_blend of one chunk in one call (tokenflow_utils.py:329-397): same arguments, same
     results bit for bit, one launch less (the gather merges the search's per-split candidates itself)."""
-    _need_gpu(tgt, piv, inv_norm, kf_out, w, residual)
+    dev = _need_gpu(tgt, piv, inv_norm, kf_out, w, residual)
     lib = _lib.load()
     tgt, piv, kf_out = tgt.contiguous(), piv.contiguous(), kf_out.contiguous()
     K, S, D = piv.shape
@@ -189,22 +216,52 @@ def propagate(tgt: torch.Tensor, piv: torch.Tensor, inv_norm: torch.Tensor, kf_i
         residual = residual.contiguous()
     out = torch.empty(3 * n, S, D, dtype=out_dtype, device=kf_out.device)
     ws = _workspace(lib.tf_nn_gather_blend_workspace_bytes(n_tgt, S, D, P), tgt.device, "nn")
-    _lib.check(lib.tf_nn_gather_blend(tgt.data_ptr(), piv.data_ptr(), inv_norm.data_ptr(), kf_out.data_ptr(),
-                                      w.data_ptr() if w is not None else 0,
-                                      residual.data_ptr() if residual is not None else 0, out.data_ptr(),
-                                      K, n, S, D, P, int(kf_ids[0]), int(kf_ids[1]) if P == 2 else 0,
-                                      _DT[tgt.dtype], _DT[kf_out.dtype],
-                                      _DT[residual.dtype] if residual is not None else 0, _DT[out_dtype],
-                                      ws.data_ptr(), ws.numel(), _stream()), "tf_nn_gather_blend")
+    _launch(dev, "tf_nn_gather_blend", lib.tf_nn_gather_blend, tgt.data_ptr(), piv.data_ptr(), inv_norm.data_ptr(),
+            kf_out.data_ptr(), w.data_ptr() if w is not None else 0,
+            residual.data_ptr() if residual is not None else 0, out.data_ptr(),
+            K, n, S, D, P, int(kf_ids[0]), int(kf_ids[1]) if P == 2 else 0, _DT[tgt.dtype], _DT[kf_out.dtype],
+            _DT[residual.dtype] if residual is not None else 0, _DT[out_dtype], ws.data_ptr(), ws.numel())
+    return out
+
+
+def propagate_chunks(tgt: torch.Tensor, piv: torch.Tensor, inv_norm: torch.Tensor, kf_out: torch.Tensor,
+                     w: torch.Tensor, n: int, n_chunks: int, slot0: int, first_single: bool,
+                     residual: Optional[torch.Tensor], out_dtype: torch.dtype) -> torch.Tensor:
+    """`propagate` for a run of `n_chunks` consecutive chunks of n frames in one call (tf_nn_gather_blend_chunks):
+    tgt [n_chunks*n*S, D] chunk-major, residual / result [3*n_chunks*n, S, D]; chunk j matches keyframe slots
+    slot0 + j and slot0 + j - 1 of piv / inv_norm / kf_out; first_single: chunk 0 of the run is chunk 0 of the
+    video (one keyframe).  Bit-identical to n_chunks calls of `propagate`."""
+    dev = _need_gpu(tgt, piv, inv_norm, kf_out, w, residual)
+    lib = _lib.load()
+    tgt, piv, kf_out = tgt.contiguous(), piv.contiguous(), kf_out.contiguous()
+    K, S, D = piv.shape
+    C = int(n_chunks)
+    if C == 1:
+        ids = [slot0] if first_single else [slot0, slot0 - 1]
+        return propagate(tgt, piv, inv_norm, ids, kf_out, None if first_single else w, n, residual, out_dtype)
+    if (tgt.dtype != piv.dtype or tgt.shape != (C * n * S, D) or kf_out.shape != (3 * K, S, D) or w is None
+            or slot0 + C > K or slot0 < (0 if first_single else 1)):
+        raise ValueError("propagate_chunks: bad arguments")
+    if residual is not None:
+        residual = residual.contiguous()
+    # what the reference's single-keyframe pass would emit for chunk 0: kf dtype (+ residual), torch promotion
+    single_dtype = kf_out.dtype if residual is None else torch.promote_types(kf_out.dtype, residual.dtype)
+    out = torch.empty(3 * C * n, S, D, dtype=out_dtype, device=kf_out.device)
+    ws = _workspace(lib.tf_nn_gather_blend_chunks_workspace_bytes(n * S, S, D, C), tgt.device, "nn")
+    _launch(dev, "tf_nn_gather_blend_chunks", lib.tf_nn_gather_blend_chunks, tgt.data_ptr(), piv.data_ptr(),
+            inv_norm.data_ptr(), kf_out.data_ptr(), w.data_ptr(), residual.data_ptr() if residual is not None else 0,
+            out.data_ptr(), K, n, C, S, D, int(slot0), 1 if first_single else 0, _DT[tgt.dtype], _DT[kf_out.dtype],
+            _DT[residual.dtype] if residual is not None else 0, _DT[out_dtype], _DT[single_dtype],
+            ws.data_ptr(), ws.numel())
     return out
 
 
 def inject_copy_(x: torch.Tensor) -> torch.Tensor:
     """In place: x[n:2n] = x[:n]; x[2n:] = x[:n] with n = len(x)//3 (tokenflow_utils.py:87-91)."""
-    _need_gpu(x)
+    dev = _need_gpu(x)
     lib = _lib.load()
     if x.shape[0] % 3 or not x.is_contiguous():
         raise ValueError("inject_copy_: need a contiguous tensor whose batch is a multiple of 3")
     per_branch = x.numel() // 3
-    _lib.check(lib.tf_inject_copy(x.data_ptr(), per_branch, x.element_size(), _stream()), "tf_inject_copy")
+    _launch(dev, "tf_inject_copy", lib.tf_inject_copy, x.data_ptr(), per_branch, x.element_size())
     return x
