@@ -208,6 +208,15 @@ def test_multi_chunk_pass_equals_per_chunk_passes(fake_ops, first):
         blk(x_all, encoder_hidden_states=enc_n)
 
 
+def test_cfg1_harness_dry_run_on_cpu(monkeypatch):
+    """The config-1 end-to-end harness of tests/test_baseline_configs_gpu.py (public installers, the driver's call
+    sequence, per-op oracle checks, block outputs against `oracle.block_forward`) run on the CPU with the
+    oracle-backed ops standing in for the HIP library: validates the harness itself and the host logic at the
+    real SD1.5 widths, one step."""
+    from tests import test_baseline_configs_gpu as e2e
+    e2e.run_cfg1(FakeOps(round16=True), torch.device("cpu"), monkeypatch, steps=[0], full_steps={0})
+
+
 def test_fused_qkv_equals_three_projections(fake_ops, monkeypatch):
     """Row f2: q, k, v as column slabs of one GEMM against the cached concatenated weight -- on CPU the fused
     path is disabled (x.is_cuda), so emulate it by calling the helper's math directly: the slabs must equal the

@@ -38,13 +38,15 @@ def _ops():
     return ops
 
 
-def attn_ref(q, k, v, h, scale, inject):
+def attn_ref(q, k, v, h, scale, inject, need_sigma=True):
     """(oracle output, softmax.|V|, sigma) -- softmax.|V| drives the P-rounding term of the bound, sigma the
     q*scale rounding term of the folded-scale kernels (Dh = 40): per query, the largest standard deviation over
     its keys of the score perturbation caused by rounding q*c to 8 significant bits,
     sigma = 2^-9/sqrt(3) * scale * max_k sqrt(sum_d (q_d k_d)^2)."""
     B, S, D = q.shape
     K, d = B // 3, D // h
+    if not need_sigma:
+        return (orc.ext_attn_core(q, k, v, h, scale, inject), orc.ext_attn_core(q, k, v.abs(), h, scale, inject), None)
     qs = (q.view(3, K, S, h, d) ** 2)
     ks = (k.view(3, K, S, h, d) ** 2)
     if inject:
