@@ -39,10 +39,11 @@ extern "C" {
 
 /* tf_ext_attn_fwd flags (the `inject` argument is a bit mask) */
 #define TF_ATTN_INJECT 1       /* q/k injection: uncond and cond use the source branch's q and k */
-#define TF_ATTN_EXACT_SCALE 2  /* scale the scores in fp32 (no folding of scale*log2e into q) */
+#define TF_ATTN_EXACT_SCALE 2  /* scale the scores in fp32: the default since ABI 2, the bit is accepted and ignored */
 #define TF_ATTN_BANK_ONLY 4    /* compute only the uncond and cond branches (those that read the K-frame bank) */
 #define TF_ATTN_SOURCE_ONLY 8  /* compute only the source branch (own-frame keys) */
 #define TF_ATTN_NO_SPLIT 16    /* never split a bank problem over workgroups (one pass, bit-stable across grid sizes) */
+#define TF_ATTN_FOLD_SCALE 64  /* Dh = 40 only: fold scale*log2e into q, rounded to the input dtype (faster, less exact) */
 #define TF_ATTN_OUT_F32 32     /* `out` is float: the normalised fp32 accumulator, without the rounding to the 16-bit I/O type */
 
 /* argument errors */
@@ -74,9 +75,11 @@ const char* tf_last_error(void);
  *   174-179) -- the bank is read in place, never replicated.
  *   inject & TF_ATTN_INJECT: uncond and cond use the SOURCE branch's q and k (124-130),
  *   by pointer aliasing; q and k are not modified.
- *   inject & TF_ATTN_EXACT_SCALE: at Dh = 40 the kernel by default folds scale*log2(e) into q (rounded
- *   to the input dtype once, relative error <= 2^-9 per element; +12 % speed); this flag keeps the
- *   reference's fp32 scaling of the scores.  No effect at other head dims.
+ *   The scores are scaled in fp32 after the QK^T product, as the reference does (`* self.scale`, 173-175).
+ *   inject & TF_ATTN_FOLD_SCALE (opt-in, Dh = 40 only): scale*log2(e) is folded into q, rounded to the input dtype
+ *   once (relative error <= 2^-9 per element in bf16): several % faster, inside the parity bound on unit-variance
+ *   logits but 3-12x outside it on peaked ones (logit std 4-16; profiles/r02_fold_accuracy.txt) -- a speed knob
+ *   for callers who accept that, never the default.
  *   scale = attn.scale (Dh^-0.5).  Dh in {40, 64, 80, 160}; dtype bf16 or f16;
  *   any S >= 1 (latent grids of odd resolutions: 9x5 = 45 tokens at the mid block of 576x320);
  *   ld a multiple of 8.  fp32 softmax / accumulation, online softmax over

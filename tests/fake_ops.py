@@ -23,7 +23,7 @@ class FakeOps:
     def compute_dtype(self, t):
         return t.dtype
 
-    def ext_attn(self, q, k, v, heads, scale, inject, out=None, q_frame0=0, exact_scale=None, part="all",
+    def ext_attn(self, q, k, v, heads, scale, inject, out=None, q_frame0=0, fold_scale=None, part="all",
                  out_dtype=None):
         self.calls.append(("ext_attn", tuple(q.shape), bool(inject)) + ((part,) if part != "all" else ()))
         K, Kq = k.shape[0] // 3, q.shape[0] // 3

@@ -9,6 +9,7 @@ LIB_PATH = os.environ.get("TOKENFLOW_HIP_LIB") or os.path.join(_HERE, "libtokenf
 TF_BF16, TF_F16, TF_F32 = 0, 1, 2
 TF_ATTN_INJECT, TF_ATTN_EXACT_SCALE, TF_ATTN_BANK_ONLY, TF_ATTN_SOURCE_ONLY, TF_ATTN_NO_SPLIT = 1, 2, 4, 8, 16
 TF_ATTN_OUT_F32 = 32
+TF_ATTN_FOLD_SCALE = 64
 ABI_VERSION = 2
 
 _c = ctypes

@@ -63,9 +63,9 @@ struct AttnParams {
     const void* q;
     const void* k;
     const void* vt;
-    const float* knorm2;  // [3][H][K*Spad/64] max |k|^2 per 64-key block, FOLD kernels only (from vt_pack_kernel)
+    const float* knorm2;  // [3][H][K*Spad/64] max |k|^2 per 64-key block, Dh = 40 kernels only (from vt_pack_kernel)
     void* out;
-    int K, Kq, q_frame0, S, H, Spad, nQT, inject, exact_scale;
+    int K, Kq, q_frame0, S, H, Spad, nQT, inject, fold;   // fold: TF_ATTN_FOLD_SCALE (Dh = 40 only)
     int part;  // 0 = all three branches, TF_ATTN_BANK_ONLY, TF_ATTN_SOURCE_ONLY
     int out_f32;       // TF_ATTN_OUT_F32: `out` is float (the normalised fp32 accumulator, no 16-bit rounding)
     int nseg;          // > 1: every bank problem is split into nseg runs of bank frames (small grids, see split_plan)
@@ -109,7 +109,7 @@ __device__ __forceinline__ int swap23(int x) { return (x & ~12) | ((x & 4) << 1)
 // zero for keys >= S.  grid = (Spad/64, H, 3*K), 256 threads; one workgroup = 64 keys x DH of one head.
 // 16-byte global accesses on both sides (rows of V in, 8 consecutive positions of one V^T row out); the
 // transpose itself is 2-byte LDS reads of a [64][DH+2] tile (odd dword stride: conflict-free columns).
-// With k != nullptr (FOLD kernels) the same workgroup also writes max |k|^2 over its 64 keys of this head to
+// With k != nullptr (Dh = 40 kernels) the same workgroup also writes max |k|^2 over its 64 keys of this head to
 // knorm2[(b*H + h) * K*Spad/64 + f*Spad/64 + tt]: the score bound q.k <= |q| max|k| of ext_attn_kernel.
 template <typename T>
 __global__ __launch_bounds__(256) void vt_pack_kernel(const typename T::elem* __restrict__ v,
@@ -174,7 +174,8 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const typename T::elem* __
 //                     (tokenflow_utils.py:124-130), so ONE workgroup computes both: QK^T and the softmax
 //                     once, two P.V products against the two V banks (NB = 2).
 // MINW = min waves per SIMD for the register allocator
-// FQ   = fold the softmax scale into Q (see FOLD below); false = exact fp32 scaling of the scores
+// FQ   = fold the softmax scale into Q (see FOLD below; opt-in, TF_ATTN_FOLD_SCALE); false = the default, fp32
+//        scaling of the scores as the reference does (tokenflow_utils.py:173-175 `* self.scale` on the bmm output)
 template <typename T, int DH, int QT, int NW, int MODE, int MINW, int KT, bool FQ>
 __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     typedef AttnCfg<DH, KT> C;
@@ -207,7 +208,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     //   shift, numerator and denominator see the same P, so no accuracy is traded for the deferral.
     //   What IS traded: q*c is rounded to 16 bit once, a relative error <= 2^-9 per element that perturbs each
     //   score by ~2^-9/sqrt(3) * c * sqrt(sum_d (q_d k_d)^2) -- the size class of the P rounding for ordinary
-    //   scores, larger for very peaked softmaxes (|score| >> 1).  TF_ATTN_EXACT_SCALE selects the fp32 scaling.
+    //   scores, but 3-12x the whole error budget on peaked softmaxes (logit std 4-16, profiles/r02_fold_accuracy.txt):
+    //   NOT the default; TF_ATTN_FOLD_SCALE opts in.
     constexpr bool FOLD = FQ && ONES && (C::DKP > DH);
     constexpr int SH_T = DH / 16, SH_HI = (DH % 16) / 8;   // k-step and lane half that hold column Dh
     //   Most tiles never look at their maximum: |acc + shift| = |q'.k| <= |q'| max_k|k| (Cauchy-Schwarz; the
@@ -219,7 +221,18 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     //   per-tile bound from the block's own max |k| measured slower than the fallback it avoids).
     //   Measured (MI355X, cfg2 level 0): -6.5 % kernel time for +7..15 us in the pre-pass.
     constexpr float FOLD_T = std::is_same<E, _Float16>::value ? 14.0f : 60.0f;
-    constexpr bool BOUND = FOLD;
+    // BOUND (Dh = 40, both scalings): the Cauchy-Schwarz score bound described above lets a wave skip the per-tile
+    // maximum.  With fp32 scaling the running "maximum" m_run becomes a deferred shift exactly as in the folded
+    // form: it is set from the first tile's maximum and moved only when a tile maximum exceeds it by more than
+    // FOLD_T binades; P = exp2((s - m_run) c) may then exceed 1 (<= 2^FOLD_T), numerator and denominator see the
+    // same P.  Saves the 16 v_max3 + permlane of most tiles and most O rescales.
+#ifndef TF_TUNE_BOUND_EXACT
+#define TF_TUNE_BOUND_EXACT 1     // A/B knobs of the round-2 experiments (tools/build_variants.sh); defaults = shipped form
+#endif
+#ifndef TF_TUNE_SCALAR_FMA
+#define TF_TUNE_SCALAR_FMA 0
+#endif
+    constexpr bool BOUND = DH == 40 && (FOLD || TF_TUNE_BOUND_EXACT);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     auto sK = [&](int buf) { return reinterpret_cast<E*>(smem) + buf * BUF_ELEMS; };
@@ -318,7 +331,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
             }
         }
     }
-    float s_bound[QT] = {};   // FOLD: upper bound of q'.k over every key of the bank (1e-3 covers the fp32 rounding)
+    float s_bound[QT] = {};   // BOUND: upper bound of q.k*c (log2 units) over every key of the bank (1.001 covers fp32 rounding)
     if constexpr (BOUND) {
         const int ppf = p.Spad / 64;   // 64-key blocks per frame; this problem sees frames f_lo .. f_lo + n_fr - 1
         const float* part = p.knorm2 + ((int64_t)(bq * H + h) * K + f_lo) * ppf;
@@ -335,7 +348,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) q2 = fmaf((float)qf[qi][t][j], (float)qf[qi][t][j], q2);
             q2 += __shfl_xor(q2, 32);   // the two lanes of a query hold disjoint halves of its columns
-            s_bound[qi] = __builtin_sqrtf(q2) * kn;
+            s_bound[qi] = __builtin_sqrtf(q2) * kn * (FOLD ? 1.f : p.c);   // log2 units in both forms
         }
     }
 
@@ -505,10 +518,27 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
                         for (int r = 0; r < 16; ++r)
                             pf[kt * 2 + (r >> 3)][r & 7] = (E)__builtin_amdgcn_exp2f(s[qi][kt][r]);
                 } else {
-                    const float mx = tile_max();
-                    // rescale only when some query of this wave saw a new maximum: alpha == 1 exactly otherwise
-                    if (__any(mx > m_run[qi])) {
-                        const float m_new = fmaxf(m_run[qi], mx);
+                    bool move;      // wave-uniform: some query's shift / running maximum changes on this tile
+                    float m_new;
+                    if constexpr (BOUND) {
+                        // m_run = deferred shift (raw-score units; -inf before the first tile, so the first tile
+                        // always looks and always moves).  No tile can overflow while (bound - shift) <= FOLD_T.
+                        const bool look = __any(s_bound[qi] - m_run[qi] * c > FOLD_T);
+                        move = false;
+                        m_new = m_run[qi];
+                        if (look) {
+                            const float mx = tile_max();
+                            const bool over = (mx - m_run[qi]) * c > FOLD_T;
+                            move = __any(over);
+                            if (over) m_new = mx;
+                        }
+                    } else {
+                        const float mx = tile_max();
+                        // rescale only when some query of this wave saw a new maximum: alpha == 1 exactly otherwise
+                        move = __any(mx > m_run[qi]);
+                        m_new = fmaxf(m_run[qi], mx);
+                    }
+                    if (move) {
                         const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);  // exp2(-inf) = 0 on tile 0
                         m_run[qi] = m_new;
                         if constexpr (!ONES) l_run[qi] *= alpha;
@@ -526,7 +556,11 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
                     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                         for (int r = 0; r < 16; r += 2) {
+#if TF_TUNE_SCALAR_FMA
+                            const float x[2] = {fmaf(s[qi][kt][r], c, -mc), fmaf(s[qi][kt][r + 1], c, -mc)};
+#else
                             const f32x2 x = f32x2{s[qi][kt][r], s[qi][kt][r + 1]} * c2 - mc2;  // v_pk_fma_f32
+#endif
                             const float p0 = __builtin_amdgcn_exp2f(x[0]);
                             const float p1 = __builtin_amdgcn_exp2f(x[1]);
                             if constexpr (!ONES) lsum += p0 + p1;
@@ -699,7 +733,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
 // How many runs of bank frames a bank problem is split into.  The grid of a sharded rank or of a small level has
 // too few waves to fill the chip (8-GPU rank at cfg2 level 0: 2 waves per SIMD, level 1: 0.5; single GPU at the
 // 16x16 level: 1): split until it has `occ` waves per SIMD, while a run keeps at least 2 tiles.
-static int split_plan(int K, int Kq, int S, int H, int Dh, bool inject, bool exact_scale, int part, bool allow) {
+static int split_plan(int K, int Kq, int S, int H, int Dh, bool inject, int part, bool allow) {
     if (!allow || part == TF_ATTN_SOURCE_ONLY) return 1;
     const bool dual = inject && S >= 256 && Dh != 160;
     const int occ = Dh == 40 ? (dual ? 3 : 4) : Dh == 160 ? 1 : (dual ? 2 : 3);   // waves per SIMD the kernels reach
@@ -708,7 +742,6 @@ static int split_plan(int K, int Kq, int S, int H, int Dh, bool inject, bool exa
     if (K * tpf < 16) return 1;   // a bank of a few tiles: the merge launch costs more than it buys (8x8 level)
     int nseg = 1;
     while (wgs * 4 * nseg < (int64_t)occ * 1024 && nseg * 2 <= K && (K / (nseg * 2)) * tpf >= 2) nseg *= 2;
-    (void)exact_scale;
     return nseg;
 }
 
@@ -1145,11 +1178,11 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
         const int b_lo = bank_only ? 1 : 0, b_hi = src_only ? 1 : 3;
         dim3 grid((unsigned)(p.Spad / 64), (unsigned)p.H, (unsigned)((b_hi - b_lo) * p.K));
         const size_t lds = (size_t)64 * (DH + 2) * sizeof(E);
-        // the folded-softmax kernels of Dh = 40 also need the key norm bounds
-        const bool fold = DH == 40 && !p.exact_scale;
+        // the Dh = 40 kernels also need the key norm bounds (score bound, see BOUND)
+        const bool bound = DH == 40;
         hipLaunchKernelGGL(vt_pack_kernel<T>, grid, dim3(256), lds, st, reinterpret_cast<const E*>(v),
                            reinterpret_cast<E*>(const_cast<void*>(p.vt)),
-                           fold ? reinterpret_cast<const E*>(p.k) : nullptr, const_cast<float*>(p.knorm2),
+                           bound ? reinterpret_cast<const E*>(p.k) : nullptr, const_cast<float*>(p.knorm2),
                            p.inject, b_lo * p.K, p.K, p.S, p.H, DH, p.Spad, p.ld);
         TF_LAUNCH_CHECK("tf_ext_attn_fwd(vt_pack)");
     }
@@ -1181,7 +1214,7 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
         // -8..11 % on a sharded rank's level 0 against the 4-wave form); below that the 4-wave form (twice the
         // workgroups).  S < 256: always 4 waves.
         const bool big = p.S >= 256 && (int64_t)3 * p.Kq * ((p.S + 255) / 256) * p.H * p.nseg >= 768;
-        if (p.exact_scale)   // fp32 score scaling (TF_ATTN_EXACT_SCALE)
+        if (!p.fold)   // fp32 score scaling: the default
             return compose([&] { return big ? launch_one<T, DH, 1, 8, MODE_ALL, 2, false>(p, st)
                                             : launch_one<T, DH, 1, 4, MODE_ALL, 2, false>(p, st); },
                            [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 3, false>(p, st); },
@@ -1229,7 +1262,7 @@ extern "C" size_t tf_ext_attn_workspace_bytes(int K, int S, int H, int Dh, int d
     size_t part_elems = 0;   // split form: worst case over the number of query frames a caller may pass
     for (int Kq = 1; Kq <= K; ++Kq)
         for (int inj = 0; inj < 2; ++inj) {
-            const int ns = split_plan(K, Kq, S, H, Dh, inj != 0, false, 0, true);
+            const int ns = split_plan(K, Kq, S, H, Dh, inj != 0, 0, true);
             const size_t e = ns > 1 ? (size_t)2 * Kq * H * S * ns * (Dh + 8) : 0;
             part_elems = e > part_elems ? e : part_elems;
         }
@@ -1269,9 +1302,9 @@ extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void
     p.nQT = (S + 127) / 128;
     p.inject = (inject & TF_ATTN_INJECT) ? 1 : 0;
     p.part = inject & (TF_ATTN_BANK_ONLY | TF_ATTN_SOURCE_ONLY);
-    p.exact_scale = (inject & TF_ATTN_EXACT_SCALE) ? 1 : 0;
+    p.fold = (inject & TF_ATTN_FOLD_SCALE) ? 1 : 0;
     p.out_f32 = (inject & TF_ATTN_OUT_F32) ? 1 : 0;
-    p.nseg = split_plan(K, Kq, S, H, Dh, p.inject != 0, p.exact_scale != 0, p.part, !(inject & TF_ATTN_NO_SPLIT));
+    p.nseg = split_plan(K, Kq, S, H, Dh, p.inject != 0, p.part, !(inject & TF_ATTN_NO_SPLIT));
     p.partials = reinterpret_cast<float*>(
         reinterpret_cast<unsigned char*>(const_cast<float*>(p.knorm2)) +
         (((size_t)3 * H * K * (((S + 127) / 128) * 128 / 64) * sizeof(float) + 255) & ~(size_t)255));

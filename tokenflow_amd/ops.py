@@ -61,8 +61,9 @@ def _workspace(nbytes: int, device, tag: str = "attn") -> torch.Tensor:
     return ws
 
 
-# TOKENFLOW_EXACT_SCALE=1: fp32 scaling of the attention scores at head dim 40 (default: scale folded into q)
-EXACT_SCALE = os.environ.get("TOKENFLOW_EXACT_SCALE", "0") not in ("", "0")
+# TOKENFLOW_FOLD_SCALE=1: at head dim 40 fold the softmax scale into q (rounded to the input dtype): several % faster,
+# 3-12x outside the parity bound on peaked logits (profiles/r02_fold_accuracy.txt).  Default: fp32 scaling of the scores.
+FOLD_SCALE = os.environ.get("TOKENFLOW_FOLD_SCALE", "0") not in ("", "0")
 # TOKENFLOW_ATTN_NO_SPLIT=1: never split a bank problem over workgroups.  By default small grids (a sharded rank, the
 # 16x16 level) split the bank into runs of frames and merge; the merge re-associates fp32 sums, so results then
 # depend on the grid size in the last bits.  With the flag the arithmetic of a (query, head) is the same everywhere.
@@ -71,7 +72,7 @@ NO_SPLIT = os.environ.get("TOKENFLOW_ATTN_NO_SPLIT", "0") not in ("", "0")
 
 def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float,
              inject: bool, out: Optional[torch.Tensor] = None, q_frame0: int = 0,
-             exact_scale: Optional[bool] = None, part: str = "all",
+             fold_scale: Optional[bool] = None, part: str = "all",
              out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """Extended attention core (tokenflow_utils.py:124-197).  k,v: [3K,S,D] bf16/f16 (the bank),
     q: [3Kq,S,D] = the queries of keyframes q_frame0..q_frame0+Kq-1 (Kq = K on one GPU); last dim
@@ -108,7 +109,7 @@ def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scal
         out = torch.empty(Bq, S, D, dtype=out_dtype, device=q.device)
     elif out.dtype != out_dtype or not out.is_contiguous() or out.shape != (Bq, S, D):
         raise ValueError("ext_attn: `out` must be a contiguous [3Kq,S,D] tensor of out_dtype")
-    flags = (1 if inject else 0) | (2 if (EXACT_SCALE if exact_scale is None else exact_scale) else 0)
+    flags = (1 if inject else 0) | (_lib.TF_ATTN_FOLD_SCALE if (FOLD_SCALE if fold_scale is None else fold_scale) else 0)
     if out_dtype == torch.float32:
         flags |= _lib.TF_ATTN_OUT_F32
     flags |= {"all": 0, "bank": _lib.TF_ATTN_BANK_ONLY, "source": _lib.TF_ATTN_SOURCE_ONLY}[part]

@@ -41,8 +41,8 @@ def main():
             qc, kc, vc = q.cpu(), k.cpu(), v.cpu()
             for inject in (False, True):
                 refs = [rows_ref(qc, kc, vc, K, S, h, d, b, f, hd, rows, inject) for b, f, hd in probs]
-                for name, exact in (("folded", False), ("exact", True)):
-                    out = ops.ext_attn(q, k, v, h, d ** -0.5, inject, exact_scale=exact).float().cpu().view(3, K, S, h, d)
+                for name, fold in (("folded", True), ("fp32-scaled", False)):
+                    out = ops.ext_attn(q, k, v, h, d ** -0.5, inject, fold_scale=fold).float().cpu().view(3, K, S, h, d)
                     worst = excess = 0.0
                     mean = []
                     for (b, f, hd), (ref, ref_abs) in zip(probs, refs):
