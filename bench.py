@@ -1,32 +1,41 @@
 #!/usr/bin/env python
 """Hot-path benchmark: denoising-step frames/sec of TokenFlow's hook layer on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--graph] [--per-chunk]
 
-A *step* = one pass of the hot path over one synthetic video: for each of
-the 16 transformer blocks of the SD UNet, one extended attention over the 3K-keyframe batch
-(pivotal pass: tf_ext_attn_fwd + tf_pivot_inv_norm) and, per frame chunk, one NN search and
-one gather/blend/residual (propagation passes: tf_nn_search + tf_gather_blend).  Inputs are
-synthetic post-projection tensors resident in HBM before the timed region; the Linear /
-LayerNorm / conv layers of the UNet are diffusers' and are not part of the path.  q/k
-injection is on for every other step (the reference injects during the first 50 % of the
-timesteps, config_pnp.yaml:21).
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches itself through
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU, RCCL);
+under torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE as usual.
 
-N > 1: frames are sharded over ranks (tokenflow_amd/sharded.py): the SAME video is split,
-so scaling is "strong"; the pivotal-pass exchange (frames <-> heads all-to-all, or the bank
-all-gather with --pivotal-exchange bank) and the neighbour halo exchange run through
-torch.distributed (RCCL) inside the timed region.
+A *step* = one pass of the hot path over one synthetic video: for each of the 16
+transformer blocks of the SD UNet, one extended attention over the 3K-keyframe batch (pivotal pass:
+tf_ext_attn_fwd + tf_pivot_inv_norm) and the token propagation of every frame chunk (NN search + gather / blend /
+residual: tf_nn_gather_blend_chunks over all chunks of the block in one call; `--per-chunk` issues the reference's
+one call per chunk, tf_nn_gather_blend).  Inputs are synthetic post-projection tensors resident in HBM before the
+timed region; the Linear / LayerNorm / conv layers of the UNet are diffusers' and are not part of the path.  q/k
+injection is on for every other step (the reference injects during the first 50 % of the timesteps,
+config_pnp.yaml:21); the two states are also timed separately (`ms_per_step_inject_on/off`).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the head-dim-40
-extended attention of level 0), timed with HIP events on the launch stream inside the timed
-region; `cpu_baseline` is the CPU oracle ("port" of the reference hook path, fp32 torch CPU)
-timed on this box's host cores on a bounded sample of the same workload.
+N > 1: frames are sharded over ranks (tokenflow_amd/sharded.py): the SAME video is split, so scaling is "strong";
+the pivotal-pass exchange (frames <-> heads all-to-all, or the bank all-gather with --pivotal-exchange bank) and
+the neighbour halo exchange run through torch.distributed (RCCL) inside the timed region.
+
+Prints ONE JSON line (rank 0):
+  roofline      the dominant kernel: the head-dim-40 extended attention of level 0 WITHOUT q/k injection
+                (ext_attn_kernel<.., MODE_ALL>), HIP events on the launch stream around every such call inside the
+                timed region (the bracket includes the V^T pre-pass launch); `roofline_inject` the same for the
+                injected calls (dual-V kernel + source launch), with the flops it actually executes next to the
+                algorithmic figure.  `traffic` is the HBM byte count of one plain launch from rocprofv3 PMC passes
+                (profiles/traffic.json; collected separately, never in this run) or null.
+  parity        in-run check against the oracle (after the timed region, rank 0, N = 1): max |out - ref| of the
+                level-0 attention on sampled rows, and the tie-aware NN index mismatch rate of a level-0 chunk.
+  cpu_baseline  the CPU oracle ("port" of the reference hook path, fp32 torch CPU, the reference's own
+                bmm -> *scale -> softmax -> bmm structure) timed on this box's host cores on a bounded sample.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -51,7 +60,15 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N > 1: nccl (= RCCL); gloo lets several ranks share one GPU on a development box "
                          "(functional check of the N > 1 path, its timing means nothing)")
+    ap.add_argument("--per-chunk", action="store_true",
+                    help="issue the propagation one call per chunk (the reference's granularity) instead of one "
+                         "call per block over all chunks")
+    ap.add_argument("--graph", action="store_true",
+                    help="N = 1: capture the two step variants (injection on / off) into HIP graphs and time the "
+                         "replays (launch-bound configurations: cfg1); the roofline bracket is then measured in a "
+                         "separate eager pass after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-sample-levels", default="0,1,2,3")
     return ap.parse_args()
 
@@ -70,34 +87,48 @@ class Block:
         self.q, self.k, self.v = rnd(3 * Kl, S, D), rnd(3 * Kl, S, D), rnd(3 * Kl, S, D)
         ln = torch.nn.functional.layer_norm
         self.pivots = ln(torch.randn(Kl, S, D, generator=gen, device=dev), (D,)).to(bf)
-        # video-like targets: permuted pivot rows + noise; residual ~ N(0,1)
-        self.tgt, self.res = [], []
+        # video-like targets: permuted pivot rows + noise; residual ~ N(0,1).
+        # All local chunks in one tensor, chunk-major: tgt [Kl*n*S, D], res [3, Kl*n, S, D]
+        tgt, self.perm = [], []
         for j in range(Kl):
-            perm = torch.stack([torch.randperm(S, generator=gen, device=dev) for _ in range(n)])
-            t = self.pivots[j].float()[perm.reshape(-1)] + 0.1 * torch.randn(n * S, D, generator=gen, device=dev)
-            self.tgt.append(t.to(bf))
-            self.res.append(rnd(3 * n, S, D))
+            perm = torch.stack([torch.randperm(S, generator=gen, device=dev) for _ in range(n)]).reshape(-1)
+            tgt.append(self.pivots[j].float()[perm] + 0.1 * torch.randn(n * S, D, generator=gen, device=dev))
+            self.perm.append(perm)
+        self.tgt = torch.cat(tgt).to(bf)
+        self.res = rnd(3 * Kl * n, S, D)
         self.attn_flops = workload.attn_flops(cfg.K, S, D) * Kl / cfg.K
+        # flops the dual-V (injection) launches execute: QK^T of the bank branches once instead of twice
+        self.attn_flops_inject = self.attn_flops - 2.0 * Kl * S * D * (cfg.K * S)
 
 
-def run_step(cfg, blocks, shard, inject_on, w, events=None, exchange=None):
+def run_step(cfg, blocks, shard, inject_on, w, events=None, exchange=None, per_chunk=False):
     n = cfg.chunk
+    outs = None
     for blk in blocks:
         inj = inject_on and blk.injected and cfg.pnp
-        if events is not None and blk.lvl == 0:
+        timed = events is not None and blk.lvl == 0
+        if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        scale = (blk.D // blk.h) ** -0.5
         if shard.world == 1:
-            kf_out = ops.ext_attn(blk.q, blk.k, blk.v, blk.h, (blk.D // blk.h) ** -0.5, inj)
+            kf_out = ops.ext_attn(blk.q, blk.k, blk.v, blk.h, scale, inj)
         else:
-            kf_out = shard.pivotal_attention(blk.q, blk.k, blk.v, blk.h, (blk.D // blk.h) ** -0.5, inj, mode=exchange)
-        if events is not None and blk.lvl == 0:
+            kf_out = shard.pivotal_attention(blk.q, blk.k, blk.v, blk.h, scale, inj, mode=exchange)
+        if timed:
             e1.record()
-            events.append((e0, e1, blk.attn_flops))
+            events.append((e0, e1, inj))
         inv = ops.pivot_inv_norm(blk.pivots)
         piv_e, inv_e, kfo_e = shard.exchange_halo(blk.pivots, inv, kf_out)
-        for j in range(shard.Kl):
-            shard.propagate(j, blk.tgt[j], blk.res[j], piv_e, inv_e, kfo_e, w, n)
+        if per_chunk:
+            nS = n * blk.S
+            res = blk.res.view(3, shard.Kl, n, blk.S, blk.D)
+            for j in range(shard.Kl):
+                outs = shard.propagate(j, blk.tgt[j * nS:(j + 1) * nS], res[:, j].reshape(3 * n, blk.S, blk.D),
+                                       piv_e, inv_e, kfo_e, w, n)
+        else:
+            outs = shard.propagate_all(blk.tgt, blk.res, piv_e, inv_e, kfo_e, w, n)
+    return outs
 
 
 def blend_w(n, dev):
@@ -121,10 +152,11 @@ def usable_cores():
 
 def cpu_baseline(cfg, levels):
     """Time the CPU oracle on a bounded sample and extrapolate to one full step.
-    Sample: per level, ONE frame (all heads unless the score matrices pass 16 GB, batched as the reference's bmm is) of the bank problem
-    (its queries against the full K*S-key bank) and of the source problem, ONE chunk of NN search (two
-    keyframes) and ONE chunk of gather/blend; scaled by heads x frames x branches, chunk count and block
-    count.  About 10 s of CPU work at cfg2 (each piece runs three times: warm-up + best of two)."""
+    Sample: per level, ONE query frame (all heads, all three branches: the source problem and the two bank
+    problems against the full K*S-key bank) through `oracle.ext_attn_core_bmm` -- the reference's own
+    bmm -> *scale -> softmax -> bmm per head (tokenflow_utils.py:172-179) -- ONE chunk of NN search (two
+    keyframes) and ONE chunk of gather/blend; scaled by frames, chunk count and block count.  About 10 s of CPU
+    work at cfg2 (each piece runs three times: warm-up + best of two)."""
     from oracle import tokenflow_oracle as orc
     torch.set_num_threads(usable_cores())
     K, n, C = cfg.K, cfg.chunk, cfg.K
@@ -147,18 +179,9 @@ def cpu_baseline(cfg, levels):
         nblk = sum(1 for l, _ in workload.BLOCKS if l == lvl)
         if lvl not in levels:
             continue
-        # heads in the sample: all of them while scores + softmax (2 x hs*S*K*S fp32) stay under 16 GB of host
-        # memory (8.6 GB at cfg2 level 0; the reference materialises the same matrices, tokenflow_utils.py:173-179)
-        hs = max(1, min(h, int(16e9 // (8.0 * S * K * S))))
-        q = torch.randn(hs, S, d, generator=g)
-        kb, vb = torch.randn(hs, K * S, d, generator=g), torch.randn(hs, K * S, d, generator=g)
-
-        def attn(kk, vv):
-            sim = torch.bmm(q, kk.transpose(-1, -2)) * d ** -0.5        # tokenflow_utils.py:173-175
-            return torch.bmm(sim.softmax(dim=-1), vv)                   # :177-179
-        t_bank, _ = timed(lambda: attn(kb, vb))
-        t_src, _ = timed(lambda: attn(kb[:, :S], vb[:, :S]))
-        t_attn = K * (h / hs) * (2 * t_bank + t_src)
+        q, kb, vb = (torch.randn(3 * K, S, D, generator=g) for _ in range(3))
+        t_frame, _ = timed(lambda: orc.ext_attn_core_bmm(q, kb, vb, h, d ** -0.5, False, frames=[K // 2]))
+        t_attn = K * t_frame
         piv = torch.randn(K, S, D, generator=g)
         tgt = torch.randn(n, S, D, generator=g)
         kf_out = torch.randn(3 * K, S, D, generator=g)
@@ -167,23 +190,88 @@ def cpu_baseline(cfg, levels):
         t_gb2, _ = timed(lambda: orc.gather_blend(kf_out, idx, 1, n, residual=res))   # :362-397
         t_prop = (C - 0.5) * t_nn2 + (C - 0.5) * t_gb2                  # chunk 0 matches one keyframe (~half)
         total += nblk * (t_attn + t_prop)
-        t_spent += t_bank + t_src + t_nn2 + t_gb2
-        parts.append(f"L{lvl}: bank {t_bank:.2f}s src {t_src:.2f}s nn {t_nn2:.2f}s gather {t_gb2:.2f}s")
+        t_spent += t_frame + t_nn2 + t_gb2
+        parts.append(f"L{lvl}: attn frame {t_frame:.2f}s nn {t_nn2:.2f}s gather {t_gb2:.2f}s")
     return dict(value=cfg.frames / total, unit="frames/s", cores=torch.get_num_threads(), kind="port",
-                sample=("oracle (fp32 torch CPU restatement of the reference hooks) timed per level on one "
-                        "frame (all heads, memory permitting) of the bank+source attention, one 2-keyframe NN-search chunk and one "
-                        "gather/blend chunk, extrapolated by heads*frames*branches, chunks and blocks to a full "
-                        f"step ({total:.1f} s/step extrapolated from {t_spent:.1f} s of best-of-2 samples; " + "; ".join(parts) + ")"))
+                sample=("oracle (fp32 torch CPU restatement of the reference hooks; attention = "
+                        "oracle.ext_attn_core_bmm, the reference's per-head bmm/softmax/bmm) timed per level on one "
+                        "query frame (all heads, source + two bank problems), one 2-keyframe NN-search chunk and "
+                        "one gather/blend chunk, extrapolated by frames, chunks and blocks to a full "
+                        f"step ({total:.1f} s/step extrapolated from {t_spent:.1f} s of best-of-2 samples; "
+                        + "; ".join(parts) + ")"))
+
+
+def parity_check(cfg, blocks, w):
+    """In-run parity on the level-0 block (rank 0, N = 1): attention L_inf against the fp32 oracle on sampled
+    query rows of six (branch, frame, head) problems, with and without injection; tie-aware NN index mismatch
+    rate of one chunk on sampled targets (tolerance 1e-5 on the fp32 cosine similarity), and the propagation
+    output of those rows against the oracle's gather/blend (bit-exact when the indices agree)."""
+    from oracle import tokenflow_oracle as orc
+    blk = next(b for b in blocks if b.lvl == 0 and b.injected)
+    K, n, S, D, h = cfg.K, cfg.chunk, blk.S, blk.D, blk.h
+    d = D // h
+    qc, kc, vc = (t.float().cpu().view(3, K, S, h, d) for t in (blk.q, blk.k, blk.v))
+    rows = torch.arange(3, S, max(S // 24, 1))
+    worst = {}
+    for inject in ((False, True) if cfg.pnp else (False,)):
+        out = ops.ext_attn(blk.q, blk.k, blk.v, h, d ** -0.5, inject).float().cpu().view(3, K, S, h, d)
+        err = 0.0
+        for b, f, head in [(0, 0, 0), (0, K - 1, h - 1), (1, 0, h // 2), (1, K - 1, 0), (2, K // 2, h - 1), (2, K - 2, 1)]:
+            bq = 0 if (inject and b > 0) else b
+            qr = qc[bq, f, rows, head]
+            if b == 0:
+                kk, vv = kc[0, f, :, head], vc[0, f, :, head]
+            else:
+                kk, vv = kc[bq, :, :, head].reshape(K * S, d), vc[b, :, :, head].reshape(K * S, d)
+            ref = torch.softmax(qr @ kk.T * d ** -0.5, dim=-1) @ vv          # tokenflow_utils.py:173-179
+            err = max(err, float((out[b, f, rows, head] - ref).abs().max()))
+        worst["inject" if inject else "plain"] = err
+    # NN search + propagation of chunk c on sampled targets
+    c = min(3, K - 1)
+    nS = n * S
+    inv = ops.pivot_inv_norm(blk.pivots)
+    ids = [c, c - 1] if c > 0 else [c]
+    tgt = blk.tgt[c * nS:(c + 1) * nS]
+    idx = ops.nn_search(tgt, blk.pivots, inv, ids).cpu()
+    sample = torch.randperm(nS, generator=torch.Generator().manual_seed(0))[:2048]
+    sim = orc.batch_cosine_sim(tgt[sample.to(tgt.device)].float().cpu(),
+                               blk.pivots[ids].float().cpu().reshape(-1, D))
+    n_diff = n_bad = 0
+    for p_, s_ in enumerate(sim.chunk(len(ids), dim=1)):
+        a, b_ = orc.nn_mismatch_tie_aware(s_, s_.argmax(-1), idx[p_][sample], 1e-5)
+        n_diff += a
+        n_bad += b_
+    total = len(ids) * len(sample)
+    return {"attn_linf": round(max(worst.values()), 6), "attn_linf_by_state": {k: round(v, 6) for k, v in worst.items()},
+            "attn_rows_checked": int(len(rows)) * 6 * len(worst), "tolerance": 1e-3,
+            "nn_mismatch_rate": n_bad / total, "nn_index_diff_rate": n_diff / total, "nn_targets_checked": total,
+            "reference": "oracle (fp32 CPU restatement pinned to the verbatim reference, tests/golden/)"}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: become `torch.distributed.run` with N ranks on this node."""
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and n_dev < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible "
+                 f"(use --backend gloo to let ranks share a GPU for a functional check)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, cmd)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE {world}")
     if args.backend == "gloo":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -205,61 +293,117 @@ def main():
     exch_name = (names[exchange] if exchange else names["heads"] if n_heads_ok == len(cfg.levels)
                  else names["bank"] if n_heads_ok == 0
                  else "frames<->heads all-to-all on the levels whose heads divide over the ranks, K/V bank all-gather on the others")
+    use_graph = args.graph and world == 1
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step(i, events=None):
+        return run_step(cfg, blocks, shard, i % 2 == 0, w, events, exchange=exchange, per_chunk=args.per_chunk)
+
     for i in range(args.warmup):
-        run_step(cfg, blocks, shard, i % 2 == 0, w, exchange=exchange)
-    events = []
+        step(i)
+    graphs = None
+    if use_graph:
+        from tokenflow_amd.graphs import GraphCache
+        graphs = GraphCache(warmup=0)
+        for i in range(2):          # capture both injection states before the timed region
+            graphs.run(("step", i % 2), lambda i=i: step(i))
+    events, marks = [], []
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        run_step(cfg, blocks, shard, i % 2 == 0, w, events, exchange=exchange)
+        m = torch.cuda.Event(enable_timing=True)
+        m.record()
+        marks.append(m)
+        if use_graph:
+            graphs.run(("step", i % 2), None)
+        else:
+            step(i, events)
+    m = torch.cuda.Event(enable_timing=True)
+    m.record()
+    marks.append(m)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if use_graph:                   # roofline bracket: separate eager pass (events cannot be read out of a graph)
+        for i in range(2):
+            step(i, events)
+        torch.cuda.synchronize()
 
     ms_per_step = elapsed / args.steps * 1e3
     value = cfg.frames * args.steps / elapsed
     fa, fn, gb = workload.step_work(cfg)
-    # dominant kernel: level-0 extended attention (head dim 40 for SD1.5): algorithmic flops / launch time
-    durs = [e0.elapsed_time(e1) * 1e-3 for e0, e1, _ in events]
-    flops = events[0][2] if events else 0.0
-    avg = sum(durs) / max(len(durs), 1)
-    achieved = flops / avg / 1e12 if avg > 0 else 0.0
-    traffic = None
+    per_state = {True: [], False: []}
+    for i in range(args.steps):
+        per_state[i % 2 == 0].append(marks[i].elapsed_time(marks[i + 1]))
+    avg = lambda xs: sum(xs) / len(xs) if xs else None
+
+    blk0 = next(b for b in blocks if b.lvl == 0)
+    dh0 = cfg.levels[0][1] // cfg.levels[0][2]
+
+    def roof(inj, flops, extra=None):
+        durs = [e0.elapsed_time(e1) * 1e-3 for e0, e1, i_ in events if i_ == inj]
+        if not durs:
+            return None
+        a = sum(durs) / len(durs)
+        r = {"bound": "mfma", "achieved": round(flops / a / 1e12, 1), "peak": workload.MFMA_BF16_PEAK / 1e12,
+             "unit": "TFLOP/s", "frac": round(flops / a / workload.MFMA_BF16_PEAK, 4),
+             "avg_launch_ms": round(a * 1e3, 3), "launches_timed": len(durs),
+             "algorithmic_gflop_per_launch": round(flops / 1e9, 1)}
+        if extra:
+            r.update(extra)
+        return r
+
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.isfile(tpath):
         try:
-            traffic = json.load(open(tpath)).get(args.config, {}).get("ext_attn_l0_hbm_bytes_per_launch")
+            tj = json.load(open(tpath)).get(args.config, {})
+            traffic = tj.get("ext_attn_l0_hbm_bytes_per_launch")
+            traffic_src = tj.get("source")
         except Exception:
             traffic = None
+    plain = roof(False, blk0.attn_flops, {
+        "kernel": "ext_attn_kernel<bf16, Dh=%d, MODE_ALL> level 0, no q/k injection (+ V^T pre-pass inside the event "
+                  "bracket)" % dh0,
+        "traffic": traffic,
+        "traffic_source": traffic_src or "profiles/traffic.json (rocprofv3 --pmc passes of tools/attn_microbench.py; "
+                                         "not measured in this run)"})
+    dual = roof(True, blk0.attn_flops, {
+        "kernel": "dual-V kernel (uncond + cond share QK^T and the softmax) + source launch + V^T pre-pass, level 0, "
+                  "q/k injection on",
+        "executed_gflop_per_launch": round(blk0.attn_flops_inject / 1e9, 1),
+        "note": "achieved/frac use the ALGORITHMIC flops of the reference formulation; the launch executes fewer"})
     out = {
         "metric": "denoising-step hot-path frames/sec", "value": round(value, 2), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic",
-        "config": {"workload": cfg.name + " (hot path: 16 blocks x [ext-attn + %d x (NN-search + gather/blend)])" % cfg.K,
+        "ms_per_step_inject_on": avg(per_state[True]) and round(avg(per_state[True]), 3),
+        "ms_per_step_inject_off": avg(per_state[False]) and round(avg(per_state[False]), 3),
+        "config": {"workload": cfg.name + " (hot path: 16 blocks x [ext-attn + NN-search + gather/blend over %d chunks])" % cfg.K,
                    "frames": cfg.frames, "keyframes": cfg.K, "frames_per_chunk": cfg.chunk,
                    "levels_S_D_heads": [list(l) for l in cfg.levels],
+                   "propagation_calls": "one per chunk (tf_nn_gather_blend)" if args.per_chunk
+                   else "one per block over all chunks (tf_nn_gather_blend_chunks)",
+                   "launch": "HIP-graph replay" if use_graph else "eager",
                    "parallelism": "1 GPU" if world == 1 else
                    "frames sharded over %d GPUs; pivotal pass: %s" % (world, exch_name),
                    "step_algorithmic_tflop": round((fa + fn) / 1e12, 2),
                    "step_tflops_achieved": round((fa + fn) / 1e12 / (ms_per_step * 1e-3), 1)},
-        "roofline": {"kernel": "ext_attn_kernel<bf16, Dh=%d> level 0 (+ V^T pre-pass inside the event bracket)"
-                               % (cfg.levels[0][1] // cfg.levels[0][2]),
-                     "bound": "mfma", "achieved": round(achieved, 1), "peak": workload.MFMA_BF16_PEAK / 1e12,
-                     "unit": "TFLOP/s", "frac": round(achieved * 1e12 / workload.MFMA_BF16_PEAK, 4),
-                     "avg_launch_ms": round(avg * 1e3, 3), "launches_timed": len(durs),
-                     "algorithmic_gflop_per_launch": round(flops / 1e9, 1), "traffic": traffic},
+        "roofline": plain if plain is not None else dual,
     }
+    if plain is not None and dual is not None:
+        out["roofline_inject"] = dual
     if rank == 0:
+        if world == 1 and not args.no_parity:
+            out["parity"] = parity_check(cfg, blocks, w)
         if world == 1 and not args.no_cpu_baseline:
             lv = [int(x) for x in args.cpu_sample_levels.split(",") if x != ""]
             out["cpu_baseline"] = cpu_baseline(cfg, lv)

@@ -68,16 +68,26 @@ def ext_attn_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
     return out.reshape(3 * K, S, D)
 
 
-def ext_attn_core_bmm(q, k, v, heads, scale, inject=False):
+def ext_attn_core_bmm(q, k, v, heads, scale, inject=False, frames=None):
     """Same numbers as `ext_attn_core`, with the reference's own cost
     structure (per-head `bmm` -> `* scale` -> `softmax` -> `bmm`,
     tokenflow_utils.py:172-179, and the per-frame loop of 165-168 when K > 12).
     Used as the timed CPU baseline ("port") in bench.py.  The K-fold physical
     replication of the bank (133-138 `.repeat`) is not reproduced (it only
-    costs the reference memory and time)."""
+    costs the reference memory and time).
+
+    frames: optional list of query-frame indices -- only those frames' outputs
+    are computed (against the full K-frame bank) and returned as [3*len(frames), S, D];
+    bench.py times ONE frame this way and scales by K (a bounded sample of the
+    same per-frame work)."""
     B, S, D = q.shape
     K = B // 3
     d = D // heads
+    if frames is not None:
+        sel = torch.tensor(list(frames))
+        qsel = q.view(3, K, S, D)[:, sel].reshape(-1, S, D)
+        full = _ext_attn_bmm_frames(qsel, k, v, heads, scale, inject, sel)
+        return full
     if inject:
         q = torch.cat([q[:K]] * 3)
         k = torch.cat([k[:K]] * 3)
@@ -102,6 +112,33 @@ def ext_attn_core_bmm(q, k, v, heads, scale, inject=False):
                 sim = torch.matmul(qb[f0:f0 + step, j], kb[j].transpose(-1, -2)) * scale
                 outs[1 + bi][f0:f0 + step, :, j] = torch.matmul(sim.softmax(dim=-1), vb[j])
     return torch.cat([o.reshape(K, S, D) for o in outs])
+
+
+def _ext_attn_bmm_frames(qsel, k, v, heads, scale, inject, sel):
+    """`ext_attn_core_bmm` for the query frames `sel` only: qsel [3*F, S, D]; k, v the full [3K, S, D]."""
+    B, S, D = k.shape
+    K, F = B // 3, len(sel)
+    d = D // heads
+    q3, k3, v3 = qsel.view(3, F, S, D), k.view(3, K, S, D), v.view(3, K, S, D)
+    if inject:
+        q3 = torch.stack([q3[0]] * 3)
+        k3 = torch.stack([k3[0]] * 3)
+
+    def hb(t):  # [frames, L, D] -> [frames, h, L, d]
+        f, L, _ = t.shape
+        return t.reshape(f, L, heads, d).permute(0, 2, 1, 3)
+
+    out = torch.empty(3, F, S, heads, d, dtype=qsel.dtype)
+    qs, ks, vs = hb(q3[0]), hb(k3[0][sel]), hb(v3[0][sel])
+    for j in range(heads):
+        sim = torch.bmm(qs[:, j], ks[:, j].transpose(-1, -2)) * scale          # 173
+        out[0, :, :, j] = torch.bmm(sim.softmax(dim=-1), vs[:, j])              # 177
+        for b in (1, 2):
+            kb = hb(k3[b].reshape(1, K * S, D))[0, j]
+            vb = hb(v3[b].reshape(1, K * S, D))[0, j]
+            sim = torch.matmul(hb(q3[b])[:, j], kb.transpose(-1, -2)) * scale   # 174-175
+            out[b, :, :, j] = torch.matmul(sim.softmax(dim=-1), vb)             # 178-179
+    return out.reshape(3 * F, S, D)
 
 
 def should_inject(t, injection_schedule) -> bool:

@@ -787,7 +787,7 @@ struct PpSchedule {
 // gaps of the other stream's MFMAs.  K(t) lives in Kbuf[t&1], V(t) in Vbuf[t&1]; K(t+1) and V(t) are
 // written at the top of R1(t) from registers loaded one iteration earlier; ONE barrier per tile
 // (between R1 and R2) orders all LDS hazards (see the per-line comments).
-template <typename T, int DH, int MODE, int MINW>
+template <typename T, int DH, int MODE, int MINW, bool FQ = false>
 __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
     typedef AttnCfg<DH, 64> C;
     typedef typename T::elem E;
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
     constexpr int ONES_R = ((DH % 32) & 3) + 4 * ((DH % 32) >> 3);
     constexpr int NMFMA = 2 * C::KS + 4 * C::MT;   // MFMAs per region: one QK^T (64 keys) + one P.V
     // softmax scale and shift folded into the QK^T MFMA (see ext_attn_kernel)
-    constexpr bool FOLD = ONES && (C::DKP > DH);
+    constexpr bool FOLD = FQ && ONES && (C::DKP > DH);
     constexpr int SH_T = DH / 16, SH_HI = (DH % 16) / 8;
     constexpr float FOLD_T = 8.0f;
 
@@ -1214,6 +1214,10 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
         // -8..11 % on a sharded rank's level 0 against the 4-wave form); below that the 4-wave form (twice the
         // workgroups).  S < 256: always 4 waves.
         const bool big = p.S >= 256 && (int64_t)3 * p.Kq * ((p.S + 255) / 256) * p.H * p.nseg >= 768;
+#ifdef TF_TUNE_PP40
+        if (!p.fold && p.S >= 512 && p.nseg == 1 && (!p.inject || bank_only == false) && !src_only && !p.inject)
+            return launch_pp<T, DH, MODE_ALL, 2>(p, st);
+#endif
         if (!p.fold)   // fp32 score scaling: the default
             return compose([&] { return big ? launch_one<T, DH, 1, 8, MODE_ALL, 2, false>(p, st)
                                             : launch_one<T, DH, 1, 4, MODE_ALL, 2, false>(p, st); },

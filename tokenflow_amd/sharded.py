@@ -221,3 +221,12 @@ class FrameShard:
         out_dtype = torch.promote_types(blend_dtype, residual.dtype) if residual is not None else blend_dtype
         return ops.propagate(tgt, piv_ext, inv_ext, ids, kf_out_ext, w if len(ids) == 2 else None, n, residual,
                              out_dtype)
+
+    def propagate_all(self, tgt_all: torch.Tensor, residual_all: torch.Tensor, piv_ext, inv_ext, kf_out_ext,
+                      w: torch.Tensor, n: int, out_dtype: torch.dtype = torch.float32):
+        """ALL local chunks in one call (tf_nn_gather_blend_chunks): tgt_all [Kl*n*S, D] chunk-major, residual_all
+        [3*Kl*n, S, D] (frames chunk-major inside each branch).  Same results as Kl calls of `propagate`, bit for
+        bit; the one-keyframe chunk 0 of the video (rank 0) is rounded to the dtype its own call would produce."""
+        o = 1 if self.world > 1 else 0
+        return ops.propagate_chunks(tgt_all, piv_ext, inv_ext, kf_out_ext, w, n, self.Kl, o, self.kf0 == 0,
+                                    residual_all, out_dtype)

@@ -5,7 +5,10 @@ part of the path (q/k/v/out projections, cross-attention, feed-forward) replaced
 is timed is the hook layer itself: norm1, dtype casts, Python, and the HIP ops.  Compare with bench.py, which
 calls the ops directly on pre-made tensors.
 
-    python tools/hooks_bench.py [cfg2] [steps] [--proj]     (--proj: keep attn1's q/k/v/out Linear layers)
+    python tools/hooks_bench.py [cfg2] [steps] [--proj] [--graph] [--all-chunks]
+      --proj        keep attn1's q/k/v/out Linear layers (default: identities)
+      --graph       replay every pass from a HIP graph (tokenflow_amd.graphs.GraphCache): one host call per pass
+      --all-chunks  ONE propagation pass over all chunks (register_batch_idx(model, range(K))) instead of K passes
 """
 import os
 import sys
@@ -44,6 +47,8 @@ def build(cfg, dev, dtype):
 
 
 PROJ = "--proj" in sys.argv      # keep the real q/k/v/out Linear layers of attn1 (default: identities)
+GRAPH = "--graph" in sys.argv
+ALL_CHUNKS = "--all-chunks" in sys.argv
 
 
 def main():
@@ -65,19 +70,36 @@ def main():
     xs_chk = [torch.randn(3 * n, cfg.levels[l][0], cfg.levels[l][1], generator=g, device=dev, dtype=dtype)
               for _, l, _ in blocks]
 
+    if ALL_CHUNKS:     # one pass carries every chunk: frames chunk-major inside each branch
+        xs_chk = [x.view(3, 1, n, *x.shape[1:]).expand(3, K, n, *x.shape[1:]).reshape(3 * K * n, *x.shape[1:]).contiguous()
+                  for x in xs_chk]
+    cache = None
+    if GRAPH:
+        from tokenflow_amd.graphs import GraphCache
+        cache = GraphCache()
+
+    def pivotal_pass(*xs):
+        tfu.register_pivotal(holder, True)
+        return [blk(x) for (blk, _, _), x in zip(blocks, xs)]
+
+    def chunk_pass(c, *xs):
+        tfu.register_pivotal(holder, False)
+        tfu.register_batch_idx(holder, range(K) if ALL_CHUNKS else c)
+        return [blk(x) for (blk, _, _), x in zip(blocks, xs)]
+
     def step(inject_on):
         for blk, _, injected in blocks:
             blk.attn1.t = 5 if inject_on else 7
         # the reference runs its UNet passes under autocast (run_tokenflow_pnp.py:220)
         with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
-            tfu.register_pivotal(holder, True)
-            for (blk, _, _), x in zip(blocks, xs_piv):
-                blk(x)
-            tfu.register_pivotal(holder, False)
-            for c in range(K):
-                tfu.register_batch_idx(holder, c)
-                for (blk, _, _), x in zip(blocks, xs_chk):
-                    blk(x)
+            if cache is not None:
+                cache.run(("pivotal", inject_on), pivotal_pass, *xs_piv)
+                for c in ([0] if ALL_CHUNKS else range(K)):
+                    cache.run(("chunk", c), lambda *xs, c=c: chunk_pass(c, *xs), *xs_chk)
+            else:
+                pivotal_pass(*xs_piv)
+                for c in ([0] if ALL_CHUNKS else range(K)):
+                    chunk_pass(c, *xs_chk)
 
     for i in range(2):
         step(i % 2 == 0)
@@ -88,7 +110,8 @@ def main():
     t_cpu = time.perf_counter() - t0
     torch.cuda.synchronize()
     t = time.perf_counter() - t0
-    print(f"hooks path, {cfg.name}: {t / steps * 1e3:.2f} ms/step ({cfg.frames * steps / t:.0f} frames/s); "
+    mode = ("graph replay" if GRAPH else "eager") + (", one pass over all chunks" if ALL_CHUNKS else "") + (", real projections" if PROJ else "")
+    print(f"hooks path [{mode}], {cfg.name}: {t / steps * 1e3:.2f} ms/step ({cfg.frames * steps / t:.0f} frames/s); "
           f"host-side issue time {t_cpu / steps * 1e3:.2f} ms/step")
 
 
