@@ -113,21 +113,32 @@ def run_step(cfg, blocks, shard, inject_on, w, events=None, exchange=None, per_c
         scale = (blk.D // blk.h) ** -0.5
         if shard.world == 1:
             kf_out = ops.ext_attn(blk.q, blk.k, blk.v, blk.h, scale, inj)
+            halo = None
         else:
+            # the pivots' halo (features + inverse norms of the last local keyframe -> rank r+1) does not depend on
+            # the attention: issued first, it travels under it
+            halo = shard.halo_start(blk.pivots, ops.pivot_inv_norm(blk.pivots))
             kf_out = shard.pivotal_attention(blk.q, blk.k, blk.v, blk.h, scale, inj, mode=exchange)
         if timed:
             e1.record()
             events.append((e0, e1, inj))
-        inv = ops.pivot_inv_norm(blk.pivots)
-        piv_e, inv_e, kfo_e = shard.exchange_halo(blk.pivots, inv, kf_out)
+        if per_chunk or shard.world == 1:
+            if halo is None:
+                piv_e, inv_e, kfo_e = shard.exchange_halo(blk.pivots, ops.pivot_inv_norm(blk.pivots), kf_out)
+            else:
+                piv_e, inv_e, kfo_e = shard.halo_finish(halo, kf_out)
         if per_chunk:
             nS = n * blk.S
             res = blk.res.view(3, shard.Kl, n, blk.S, blk.D)
             for j in range(shard.Kl):
                 outs = shard.propagate(j, blk.tgt[j * nS:(j + 1) * nS], res[:, j].reshape(3 * n, blk.S, blk.D),
                                        piv_e, inv_e, kfo_e, w, n)
-        else:
+        elif shard.world == 1:
             outs = shard.propagate_all(blk.tgt, blk.res, piv_e, inv_e, kfo_e, w, n)
+        else:
+            # the attention-output halo travels under the propagation of the local chunks that do not read it
+            piv_e, inv_e, kfo_e, reqs = shard.halo_finish(halo, kf_out, wait=False)
+            outs, _ = shard.propagate_all(blk.tgt, blk.res, piv_e, inv_e, kfo_e, w, n, halo_reqs=reqs)
     return outs
 
 

@@ -106,6 +106,31 @@ int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void* out,
                     int K, int Kq, int q_frame0, int S, int H, int Dh, int64_t ld, float scale,
                     int inject, int dtype, void* ws, size_t ws_bytes, void* stream);
 
+/* The same with explicit branch / frame strides (elements), for callers whose q, k, v arrive in the layout a
+ * collective delivers them and whose output feeds the next collective (tokenflow_amd/sharded.py: the received
+ * all-to-all buffer is [frame][slab][S][H*Dh], the returned one [frame][branch][S][H*Dh]):
+ *   strides = { q_branch, q_frame, k_branch, k_frame, v_branch, v_frame, out_branch, out_frame }
+ *   element (b, f, s, c) of q is q[b*q_branch + f*q_frame + s*ld + c]; out has token stride H*Dh.
+ * Branch b of a tensor is addressed as base + b*branch_stride even when a call never touches branch 0 (bank-only
+ * calls): pass base = (first touched slab) - b*branch_stride.  tf_ext_attn_fwd is this function with dense strides. */
+int tf_ext_attn_fwd_strided(const void* q, const void* k, const void* v, void* out,
+                            int K, int Kq, int q_frame0, int S, int H, int Dh, int64_t ld, const int64_t* strides,
+                            float scale, int inject, int dtype, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Frames <-> heads re-sharding of the multi-GPU pivotal pass (no counterpart in the single-process reference;
+ * tokenflow_amd/sharded.py).  Rank r sends head group w of its Kl keyframes' slabs to rank w:
+ *   tf_head_pack:    send[w][f][i][s][0..hd)  = slab_i[f][s][w*hd .. (w+1)*hd)     i < ns <= 6 slabs, each a
+ *                    [Kl, S, ld] tensor with its own frame stride (elements); one launch for all slabs.
+ *   tf_head_unpack:  dst_b[f][s][w*hd ..)     = recv[w][f][b][s][0..hd)            b < nb <= 6 destinations.
+ * elem_bytes 2 or 4; hd*elem_bytes and ld*elem_bytes multiples of 16.
+ * ------------------------------------------------------------------------ */
+int tf_head_pack(const void* const* slabs, const int64_t* frame_strides, int ns, void* send, int W, int Kl, int S,
+                 int hd, int64_t ld, int elem_bytes, void* stream);
+
+int tf_head_unpack(const void* recv, void* const* dsts, const int64_t* frame_strides, int nb, int W, int Kl, int S,
+                   int hd, int64_t ld, int elem_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * Nearest-neighbour token search  --  replaces batch_cosine_sim + chunk + argmax:
  * util.py:61-69 and tokenflow_utils.py:335-343.

@@ -55,6 +55,46 @@ class FakeOps:
         out.view(3, -1)[computed] = o.view(3, -1)[computed]
         return out
 
+    def ext_attn_views(self, q, k, v, out, heads, scale, inject, part="all", branch0=(0, 0, 0, 0), q_frame0=0,
+                       fold_scale=None):
+        """Strided 4-D views [branches b0.., frames, S, D]: materialise dense [3F,S,D] tensors (branches a call
+        may not read stay NaN), run `ext_attn`, scatter the computed branches into the `out` view."""
+        K, Kq, S, D = k.shape[1], q.shape[1], k.shape[2], k.shape[3]
+
+        def dense(t, b0, F):
+            full = torch.full((3, F, S, D), float("nan"), dtype=t.dtype)
+            full[b0:b0 + t.shape[0]] = t
+            return full.view(3 * F, S, D)
+        qd, kd, vd = dense(q, branch0[0], Kq), dense(k, branch0[1], K), dense(v, branch0[2], K)
+        res = torch.full((3, Kq, S, D), float("nan"), dtype=out.dtype)
+        # ext_attn poisons what it may not read; NaN slabs here play the same role for what was never passed
+        qd2, kd2, vd2 = (torch.nan_to_num(t, nan=0.0) for t in (qd, kd, vd))
+        self.ext_attn(qd2, kd2, vd2, heads, scale, inject, out=res.view(3 * Kq, S, D), q_frame0=q_frame0, part=part,
+                      out_dtype=out.dtype)
+        computed = {"all": [0, 1, 2], "bank": [1, 2], "source": [0]}[part]
+        need_q = [0] if (inject or part == "source") else ([1, 2] if part == "bank" else [0, 1, 2])
+        if inject and part == "all":
+            need_q = [0]
+        need_v = computed
+        for b in need_q:
+            assert not torch.isnan(qd.view(3, -1)[b]).any() and not torch.isnan(kd.view(3, -1)[b]).any(), "unread q/k slab"
+        for b in need_v:
+            assert not torch.isnan(vd.view(3, -1)[b]).any(), "unread v slab"
+        for b in computed:
+            out[b - branch0[3]] = res[b]
+        return out
+
+    def head_pack(self, slabs, W):
+        Kl, S, D = slabs[0].shape
+        hd = D // W
+        st = torch.stack([t.reshape(Kl, S, W, hd) for t in slabs], dim=1)     # [Kl, ns, S, W, hd]
+        return st.permute(3, 0, 1, 2, 4).contiguous()                          # [W, Kl, ns, S, hd]
+
+    def head_unpack(self, recv, dsts):
+        W, Kl, nb, S, hd = recv.shape
+        for b, d in enumerate(dsts):
+            d.view(Kl, S, W, hd).copy_(recv[:, :, b].permute(1, 2, 0, 3))
+
     def pivot_inv_norm(self, piv):
         return 1.0 / self._r(piv).norm(dim=-1)
 

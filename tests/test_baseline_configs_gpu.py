@@ -456,3 +456,55 @@ def test_hipgraph_replay_of_hook_passes():
             torch.cuda.synchronize()
             assert torch.equal(got_p, want_p) and torch.equal(got_c, want_c), rep
     assert len(cache) == 2
+
+
+# ------------------------------------------------------------------------------------------- collective-shaped layouts
+@pytest.mark.parametrize("K,S,h,d", [(4, 320, 2, 40), (3, 136, 2, 64), (2, 264, 1, 80), (2, 72, 1, 160), (5, 1024, 1, 40)])
+@pytest.mark.parametrize("inject", [False, True])
+def test_ext_attn_strided_views_equal_dense(K, S, h, d, inject, monkeypatch):
+    """tf_ext_attn_fwd_strided on the buffers of the head re-sharding -- q / k / v read from a [frame][slab][S][D]
+    all-to-all receive buffer, the output written into a [frame][branch][S][D] send buffer -- must equal the dense
+    call bit for bit (one-pass form: the arithmetic of a (query, head) does not depend on the layout)."""
+    ops = _ops()
+    monkeypatch.setattr(ops, "NO_SPLIT", True)
+    D = h * d
+    g = torch.Generator(device="cuda").manual_seed(S + d)
+    q, k, v = (torch.randn(3 * K, S, D, generator=g, device="cuda").bfloat16() for _ in range(3))
+    dense = ops.ext_attn(q, k, v, h, d ** -0.5, inject, part="bank", out=torch.zeros_like(q)).view(3, K, S, D)
+    q3, k3, v3 = (t.view(3, K, S, D) for t in (q, k, v))
+    slabs = [q3[0], k3[0], v3[1], v3[2]] if inject else [q3[1], q3[2], k3[1], k3[2], v3[1], v3[2]]
+    recv = torch.stack(slabs, dim=1).contiguous()                 # [K, ns, S, D]: what the first all-to-all delivers
+    rp = recv.permute(1, 0, 2, 3)
+    send2 = torch.full((K, 2, S, D), 7.0, dtype=q.dtype, device="cuda")
+    o4 = send2.permute(1, 0, 2, 3)
+    if inject:
+        ops.ext_attn_views(rp[0:1], rp[1:2], rp[2:4], o4, h, d ** -0.5, True, "bank", branch0=(0, 0, 1, 1))
+    else:
+        ops.ext_attn_views(rp[0:2], rp[2:4], rp[4:6], o4, h, d ** -0.5, False, "bank", branch0=(1, 1, 1, 1))
+    assert torch.equal(o4, dense[1:3])
+    # full call on dense 4-D views == the 3-D call
+    full = ops.ext_attn(q, k, v, h, d ** -0.5, inject).view(3, K, S, D)
+    out = torch.empty_like(full)
+    ops.ext_attn_views(q3, k3, v3, out, h, d ** -0.5, inject)
+    assert torch.equal(out, full)
+
+
+@pytest.mark.parametrize("W,Kl,S,D,dtype", [(8, 1, 4096, 320, torch.bfloat16), (2, 3, 200, 160, torch.float16),
+                                             (4, 2, 64, 1280, torch.bfloat16), (2, 2, 45, 80, torch.float32)])
+def test_head_pack_unpack(W, Kl, S, D, dtype):
+    """tf_head_pack / tf_head_unpack against the torch formulation of the same re-layout (bit-exact: pure copies),
+    with strided source slabs (column slabs of a fused projection output)."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(W + S)
+    fused = torch.randn(3 * Kl, S, 3 * D, generator=g, device="cuda").to(dtype)
+    q3, k3, v3 = (fused[..., i * D:(i + 1) * D].unflatten(0, (3, Kl)) for i in range(3))
+    slabs = [q3[1], q3[2], k3[1], k3[2], v3[1], v3[2]]
+    hd = D // W
+    send = ops.head_pack(slabs, W)
+    want = torch.stack([t.reshape(Kl, S, W, hd) for t in slabs], dim=1).permute(3, 0, 1, 2, 4)
+    assert send.shape == (W, Kl, 6, S, hd) and torch.equal(send, want)
+    recv2 = torch.randn(W, Kl, 2, S, hd, generator=g, device="cuda").to(dtype)
+    out = torch.zeros(3, Kl, S, D, dtype=dtype, device="cuda")
+    ops.head_unpack(recv2, [out[1], out[2]])
+    assert torch.equal(out[1:3].view(2, Kl, S, W, hd), recv2.permute(2, 1, 3, 0, 4))
+    assert bool((out[0] == 0).all())

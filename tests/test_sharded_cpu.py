@@ -64,6 +64,18 @@ def _worker(rank, world, port, K, n, S, h, d, inject, mode, ret):
         for j in range(Kl):
             y = sh.propagate(j, tgt[f0 + j], res[f0 + j], piv_e, inv_e, kfo_e, w, n)
             ok = ok and torch.equal(y, full_prop[f0 + j])
+        # ---- all local chunks in one call, halo split in two halves, the first chunk deferred behind the halo
+        tgt_all = torch.cat([tgt[f0 + j] for j in range(Kl)])
+        res_all = torch.stack([res[f0 + j].view(3, n, S, D) for j in range(Kl)], dim=1).reshape(3 * Kl * n, S, D)
+        want = torch.stack([full_prop[f0 + j].view(3, n, S, D) for j in range(Kl)], dim=1).reshape(3 * Kl * n, S, D)
+        got = sh.propagate_all(tgt_all, res_all, piv_e, inv_e, kfo_e, w, n)
+        ok = ok and torch.equal(got, want)
+        h = sh.halo_start(piv[f0:f0 + Kl], inv[f0:f0 + Kl])
+        pe, ie, ke, reqs = sh.halo_finish(h, loc(kf_out), wait=False)
+        first, rest = sh.propagate_all(tgt_all, res_all, pe, ie, ke, w, n, halo_reqs=reqs)
+        ok = ok and torch.equal(first, full_prop[f0])
+        if Kl > 1:
+            ok = ok and torch.equal(rest, want.view(3, Kl, n, S, D)[:, 1:].reshape(3 * (Kl - 1) * n, S, D))
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()

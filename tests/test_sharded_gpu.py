@@ -18,12 +18,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, K, inject, mode, no_split, ret):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world, port, K, inject, mode, no_split, ret, backend="gloo"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "nccl":        # RCCL: one GPU per rank
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:                        # gloo: the ranks share cuda:0
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from tokenflow_amd import ops, sharded
-        torch.cuda.set_device(0)
         ops.NO_SPLIT = no_split
 
         n, S, h, d = 2, 320, 2, 40
@@ -53,12 +57,25 @@ def _worker(rank, world, port, K, inject, mode, no_split, ret):
             a, r = out.float(), loc(full).float()
             ok = bool(((a - r).abs() <= 2.0 ** -7 * r.abs() + 1e-3).all())
         pe, ie, ke = sh.exchange_halo(piv[f0:f0 + Kl], inv[f0:f0 + Kl], out)
-        for j in range(Kl):
-            y = sh.propagate(j, tgt[f0 + j], res[f0 + j], pe, ie, ke, w, n)
+
+        def same(y, r):
             if no_split:
-                ok = ok and torch.equal(y, ref[f0 + j])
-            else:        # same indices, gathered rows within the attention tolerance above
-                ok = ok and bool(((y.float() - ref[f0 + j].float()).abs() <= 2.0 ** -6 * ref[f0 + j].float().abs() + 2e-3).all())
+                return torch.equal(y, r)
+            # same indices, gathered rows within the attention tolerance above
+            return bool(((y.float() - r.float()).abs() <= 2.0 ** -6 * r.float().abs() + 2e-3).all())
+        for j in range(Kl):
+            ok = ok and same(sh.propagate(j, tgt[f0 + j], res[f0 + j], pe, ie, ke, w, n), ref[f0 + j])
+        # all local chunks in one call; halo in two halves with the first chunk deferred behind it
+        tgt_all = torch.cat([tgt[f0 + j] for j in range(Kl)])
+        res_all = torch.stack([res[f0 + j].view(3, n, S, D) for j in range(Kl)], dim=1).reshape(3 * Kl * n, S, D)
+        want = torch.stack([ref[f0 + j].float().view(3, n, S, D) for j in range(Kl)], dim=1).reshape(3 * Kl * n, S, D)
+        ok = ok and same(sh.propagate_all(tgt_all, res_all, pe, ie, ke, w, n), want)
+        h = sh.halo_start(piv[f0:f0 + Kl], inv[f0:f0 + Kl])
+        pe2, ie2, ke2, reqs = sh.halo_finish(h, out, wait=False)
+        first, rest = sh.propagate_all(tgt_all, res_all, pe2, ie2, ke2, w, n, halo_reqs=reqs)
+        ok = ok and same(first, ref[f0])
+        if Kl > 1:
+            ok = ok and same(rest, want.view(3, Kl, n, S, D)[:, 1:].reshape(3 * (Kl - 1) * n, S, D))
         torch.cuda.synchronize()
         ret[rank] = bool(ok)
     finally:
@@ -76,6 +93,18 @@ def test_sharded_real_kernels_two_ranks(K, mode, inject, no_split):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, K, inject, mode, no_split, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+@pytest.mark.parametrize("K,mode,inject", [(4, "heads", False), (4, "heads", True), (5, "heads", True), (4, "bank", True)])
+def test_sharded_real_kernels_two_gpus_rccl(K, mode, inject):
+    """The same comparison with one GPU per rank over RCCL (xGMI): the all-to-alls of the head re-sharding, the bank
+    all-gather and the grouped point-to-point halo on the real backend with a world of two."""
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, K, inject, mode, True, ret, "nccl"), nprocs=2, join=True)
     assert dict(ret) == {0: True, 1: True}
 
 

@@ -19,6 +19,12 @@ _SIGNATURES = {
     "tf_ext_attn_workspace_bytes": (_c.c_size_t, [_c.c_int] * 5),
     "tf_ext_attn_fwd": (_c.c_int, [_c.c_void_p] * 4 + [_c.c_int] * 6 + [_c.c_int64, _c.c_float, _c.c_int, _c.c_int,
                                    _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "tf_ext_attn_fwd_strided": (_c.c_int, [_c.c_void_p] * 4 + [_c.c_int] * 6 + [_c.c_int64, _c.c_void_p, _c.c_float,
+                                           _c.c_int, _c.c_int, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "tf_head_pack": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p] + [_c.c_int] * 4 + [_c.c_int64, _c.c_int,
+                                _c.c_void_p]),
+    "tf_head_unpack": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 5 + [_c.c_int64, _c.c_int,
+                                  _c.c_void_p]),
     "tf_pivot_inv_norm": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int, _c.c_void_p]),
     "tf_nn_search_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int, _c.c_int]),
     "tf_nn_search": (_c.c_int, [_c.c_void_p] * 4 + [_c.c_int64] + [_c.c_int] * 6 + [_c.c_void_p, _c.c_size_t,

@@ -71,6 +71,10 @@ struct AttnParams {
     int nseg;          // > 1: every bank problem is split into nseg runs of bank frames (small grids, see split_plan)
     float* partials;   // [2 banks][Kq][H][S][nseg][Dh + 8] fp32: unnormalised O, l, log2-domain shift  // K bank frames; queries = frames q_frame0 .. +Kq
     int64_t ld;
+    // branch / frame strides in elements (dense tensors: frame = S*ld, branch = frames*S*ld; out: S*H*Dh, Kq*S*H*Dh).
+    // A caller whose q / k / v arrive from a collective reads them in the layout the collective delivers and has
+    // the output written in the layout the next collective sends (tf_ext_attn_fwd_strided, sharded.py).
+    int64_t q_bs, q_fs, k_bs, k_fs, v_bs, v_fs, o_bs, o_fs;
     float c;  // scale * log2(e)
 };
 
@@ -116,7 +120,8 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const typename T::elem* __
                                                       typename T::elem* __restrict__ vt,
                                                       const typename T::elem* __restrict__ k,
                                                       float* __restrict__ knorm2, int inject, int bf0, int K,
-                                                      int S, int H, int DH, int Spad, int64_t ld) {
+                                                      int S, int H, int DH, int Spad, int64_t ld, int64_t v_bs,
+                                                      int64_t v_fs, int64_t k_bs, int64_t k_fs) {
     typedef typename T::elem E;
     typedef typename T::vec8 vec8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const typename T::elem* __
     const int ppr = DH >> 3;               // 16-B pieces per V row
     const int tt = blockIdx.x, h = blockIdx.y, bf = blockIdx.z + bf0;  // bf = b*K + f; bf0 = first (branch, frame)
     const int b = bf / K, f = bf - b * K;
-    const E* src = v + ((int64_t)bf * S) * ld + h * DH;
+    const E* src = v + b * v_bs + f * v_fs + h * DH;
     // keys of branch b without injection; with injection every branch reads the SOURCE keys, whose norms the
     // first packed branch computes
     if (k != nullptr && (!inject || b == bf0 / K) && threadIdx.x < 64) {   // wave 0: one key per lane
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const typename T::elem* __
         const int kk = tt * 64 + (int)threadIdx.x;
         float acc = 0.f;
         if (kk < S) {
-            const E* kp = k + (((int64_t)kb * K + f) * S + kk) * ld + h * DH;
+            const E* kp = k + kb * k_bs + f * k_fs + (int64_t)kk * ld + h * DH;
             for (int c8 = 0; c8 < DH; c8 += 8) {
                 const vec8 x = __builtin_bit_cast(vec8, ld16(kp + c8));
 #pragma unroll
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     const bool ragged = (S % KT) != 0;
 
     const E* qg = reinterpret_cast<const E*>(p.q);
-    const E* kg = reinterpret_cast<const E*>(p.k) + ((int64_t)bq * K * S) * p.ld + h * DH;
+    const E* kg = reinterpret_cast<const E*>(p.k) + bq * p.k_bs + h * DH;
     const int64_t vt_row = vt_row_stride(K, p.Spad);
     const E* vg[NB];
 #pragma unroll
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     for (int qi = 0; qi < QT; ++qi) {
         q_row[qi] = qt * (32 * QT * NW) + (wave * QT + qi) * 32 + l31;
         q_ok[qi] = q_row[qi] < S;
-        const E* qp = qg + (((int64_t)bq * Kq + f) * S + (q_ok[qi] ? q_row[qi] : S - 1)) * p.ld + h * DH;
+        const E* qp = qg + bq * p.q_bs + f * p.q_fs + (int64_t)(q_ok[qi] ? q_row[qi] : S - 1) * p.ld + h * DH;
 #pragma unroll
         for (int t = 0; t < C::KS; ++t) {
             const int col = 16 * t + 8 * hi;
@@ -376,7 +381,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     }
     // Tile cursors (see ext_attn_pp_kernel): uniform pointer bumps, no division per tile.
     const int k_wrap = S - (tpf - 1) * KT, v_wrap = p.Spad - (tpf - 1) * KT;
-    const E* k_next = kg + (int64_t)f_lo * S * p.ld;
+    const int64_t k_wrap_off = p.k_fs - (int64_t)(tpf - 1) * KT * p.ld;   // last tile of a frame -> first tile of the next
+    const E* k_next = kg + f_lo * p.k_fs;
     const E* v_next[NB];
 #pragma unroll
     for (int vb = 0; vb < NB; ++vb) v_next[vb] = vg[vb] + (int64_t)f_lo * p.Spad;
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
             for (int i = 0; i < NPV; ++i) rv[vb][i] = ld16(v_next[vb] + v_goff[i]);
             v_next[vb] += wrap ? v_wrap : KT;
         }
-        k_next += (int64_t)(wrap ? k_wrap : KT) * p.ld;
+        k_next += wrap ? k_wrap_off : (int64_t)KT * p.ld;
         ld_tt = wrap ? 0 : ld_tt + 1;
     };
     auto stage_write = [&](int buf) {
@@ -660,8 +666,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
                 }
             }
         } else if (PACK && q_ok[qi]) {
-            const int64_t op0 = (((int64_t)b * Kq + f) * S + q_row[qi]) * ((int64_t)H * DH) + h * DH;
-            const int64_t branch = (int64_t)Kq * S * H * DH;
+            const int64_t op0 = b * p.o_bs + f * p.o_fs + (int64_t)q_row[qi] * (H * DH) + h * DH;
+            const int64_t branch = p.o_bs;
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -678,7 +684,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
         } else if (q_ok[qi]) {
 #pragma unroll
             for (int vb = 0; vb < NB; ++vb) {
-                const int64_t op = (((int64_t)(b + vb) * Kq + f) * S + q_row[qi]) * ((int64_t)H * DH) + h * DH;
+                const int64_t op = (b + vb) * p.o_bs + f * p.o_fs + (int64_t)q_row[qi] * (H * DH) + h * DH;
 #pragma unroll
                 for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
@@ -700,7 +706,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
 // One thread per (bank, frame, head, query, 4 consecutive d).
 template <typename T>
 __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ partials, void* __restrict__ out,
-                                                         int Kq, int S, int H, int DH, int nseg, int out_f32) {
+                                                         int Kq, int S, int H, int DH, int nseg, int out_f32,
+                                                         int64_t o_bs, int64_t o_fs) {
     typedef typename T::elem E;
     typedef typename T::vec4 vec4;
     const int PS = DH + 8, dq = DH >> 2;
@@ -725,8 +732,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
         const int h = (int)(t % H);
         t /= H;
         const int f = (int)(t % Kq), vbank = (int)(t / Kq);
-        store_out4<E, vec4>(out, (((int64_t)(1 + vbank) * Kq + f) * S + q) * ((int64_t)H * DH) + h * DH + d0, num * inv,
-                            out_f32);
+        store_out4<E, vec4>(out, (1 + vbank) * o_bs + f * o_fs + (int64_t)q * (H * DH) + h * DH + d0, num * inv, out_f32);
     }
 }
 
@@ -840,7 +846,7 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
     const bool ragged = (S & 63) != 0;
 
     const E* qg = reinterpret_cast<const E*>(p.q);
-    const E* kg = reinterpret_cast<const E*>(p.k) + ((int64_t)bq * K * S) * p.ld + h * DH;
+    const E* kg = reinterpret_cast<const E*>(p.k) + bq * p.k_bs + h * DH;
     const int64_t vt_row = vt_row_stride(K, p.Spad);
     const E* vg = reinterpret_cast<const E*>(p.vt) + ((int64_t)(b * H + h) * DH) * vt_row;
 
@@ -861,7 +867,7 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
     for (int qi = 0; qi < 2; ++qi) {
         q_row[qi] = qt * 256 + (wave * 2 + qi) * 32 + l31;
         q_ok[qi] = q_row[qi] < S;
-        const E* qp = qg + (((int64_t)bq * Kq + f) * S + (q_ok[qi] ? q_row[qi] : S - 1)) * p.ld + h * DH;
+        const E* qp = qg + bq * p.q_bs + f * p.q_fs + (int64_t)(q_ok[qi] ? q_row[qi] : S - 1) * p.ld + h * DH;
 #pragma unroll
         for (int t = 0; t < C::KS; ++t) {
             const int col = 16 * t + 8 * hi;
@@ -895,7 +901,8 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
     // boundary of a ragged S (the frame's last tile is short in K, padded to Spad in V^T).  Uniform
     // pointer bumps instead of a tile -> (frame, tile-in-frame) division per load.
     const int k_wrap = S - (tpf - 1) * 64, v_wrap = p.Spad - (tpf - 1) * 64;
-    const E* k_next = kg + (int64_t)f_lo * S * p.ld;   // first row of the next K tile to load
+    const int64_t k_wrap_off = p.k_fs - (int64_t)(tpf - 1) * 64 * p.ld;
+    const E* k_next = kg + f_lo * p.k_fs;   // first row of the next K tile to load
     const E* v_next = vg + (int64_t)f_lo * p.Spad;
     int k_tt = 0, v_tt = 0;                            // its tile index within the frame
     auto load_k = [&]() {
@@ -904,7 +911,7 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
         const int clamp_off = rlim * (int)p.ld;
 #pragma unroll
         for (int i = 0; i < NPK; ++i) rk[i] = ld16(k_next + (k_row[i] <= rlim ? k_goff[i] : clamp_off + k_col[i]));
-        k_next += (int64_t)(wrap ? k_wrap : 64) * p.ld;
+        k_next += wrap ? k_wrap_off : (int64_t)64 * p.ld;
         k_tt = wrap ? 0 : k_tt + 1;
     };
     auto load_v = [&]() {
@@ -1114,7 +1121,7 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
             l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32);
         const float inv_l = 1.0f / l_tot;
         if (q_ok[qi]) {
-            const int64_t op = (((int64_t)b * Kq + f) * S + q_row[qi]) * ((int64_t)H * DH) + h * DH;
+            const int64_t op = b * p.o_bs + f * p.o_fs + (int64_t)q_row[qi] * (H * DH) + h * DH;
 #pragma unroll
             for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
@@ -1183,7 +1190,7 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
         hipLaunchKernelGGL(vt_pack_kernel<T>, grid, dim3(256), lds, st, reinterpret_cast<const E*>(v),
                            reinterpret_cast<E*>(const_cast<void*>(p.vt)),
                            bound ? reinterpret_cast<const E*>(p.k) : nullptr, const_cast<float*>(p.knorm2),
-                           p.inject, b_lo * p.K, p.K, p.S, p.H, DH, p.Spad, p.ld);
+                           p.inject, b_lo * p.K, p.K, p.S, p.H, DH, p.Spad, p.ld, p.v_bs, p.v_fs, p.k_bs, p.k_fs);
         TF_LAUNCH_CHECK("tf_ext_attn_fwd(vt_pack)");
     }
     // Every head dim has three forms: ALL (one launch, bank problems then source problems), DUAL (injection:
@@ -1195,7 +1202,7 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
         const int64_t total = (int64_t)2 * p.Kq * p.H * p.S * (DH / 4);
         const int64_t blocks = (total + 255) / 256;
         hipLaunchKernelGGL(attn_merge_kernel<T>, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st,
-                           p.partials, p.out, p.Kq, p.S, p.H, DH, p.nseg, p.out_f32);
+                           p.partials, p.out, p.Kq, p.S, p.H, DH, p.nseg, p.out_f32, p.o_bs, p.o_fs);
         TF_LAUNCH_CHECK("tf_ext_attn_fwd(merge)");
         return 0;
     };
@@ -1214,10 +1221,6 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
         // -8..11 % on a sharded rank's level 0 against the 4-wave form); below that the 4-wave form (twice the
         // workgroups).  S < 256: always 4 waves.
         const bool big = p.S >= 256 && (int64_t)3 * p.Kq * ((p.S + 255) / 256) * p.H * p.nseg >= 768;
-#ifdef TF_TUNE_PP40
-        if (!p.fold && p.S >= 512 && p.nseg == 1 && (!p.inject || bank_only == false) && !src_only && !p.inject)
-            return launch_pp<T, DH, MODE_ALL, 2>(p, st);
-#endif
         if (!p.fold)   // fp32 score scaling: the default
             return compose([&] { return big ? launch_one<T, DH, 1, 8, MODE_ALL, 2, false>(p, st)
                                             : launch_one<T, DH, 1, 4, MODE_ALL, 2, false>(p, st); },
@@ -1275,10 +1278,10 @@ extern "C" size_t tf_ext_attn_workspace_bytes(int K, int S, int H, int Dh, int d
            part_elems * sizeof(float);   // V^T image | key norm bounds | split-form partial results
 }
 
-extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void* out, int K, int Kq, int q_frame0,
-                               int S, int H, int Dh, int64_t ld, float scale, int inject, int dtype, void* ws,
-                               size_t ws_bytes, void* stream) {
-    TF_ARG(q && k && v && out && ws, TF_ERR_NULL, "tf_ext_attn_fwd: null pointer");
+extern "C" int tf_ext_attn_fwd_strided(const void* q, const void* k, const void* v, void* out, int K, int Kq,
+                                       int q_frame0, int S, int H, int Dh, int64_t ld, const int64_t* strides,
+                                       float scale, int inject, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    TF_ARG(q && k && v && out && ws && strides, TF_ERR_NULL, "tf_ext_attn_fwd: null pointer");
     TF_ARG(dtype == TF_BF16 || dtype == TF_F16, TF_ERR_DTYPE, "tf_ext_attn_fwd: dtype %d (bf16/f16 only)", dtype);
     TF_ARG(Dh == 40 || Dh == 64 || Dh == 80 || Dh == 160, TF_ERR_SHAPE,
            "tf_ext_attn_fwd: head dim %d not in {40,64,80,160}", Dh);
@@ -1286,6 +1289,10 @@ extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void
            "tf_ext_attn_fwd: K=%d S=%d H=%d ld=%lld (ld a multiple of 8, >= H*Dh)", K, S, H, (long long)ld);
     TF_ARG(Kq > 0 && q_frame0 >= 0 && q_frame0 + Kq <= K, TF_ERR_SHAPE,
            "tf_ext_attn_fwd: query frames [%d, %d) outside the %d-frame bank", q_frame0, q_frame0 + Kq, K);
+    for (int i = 0; i < 8; ++i)
+        TF_ARG(strides[i] % 8 == 0 && (i & 1 ? strides[i] >= (int64_t)(S - 1) * (i < 6 ? ld : (int64_t)H * Dh) : true),
+               TF_ERR_SHAPE, "tf_ext_attn_fwd: stride %d = %lld (multiples of 8 elements; a frame holds S token rows)", i,
+               (long long)strides[i]);
     TF_ARG(tf_aligned16(q) && tf_aligned16(k) && tf_aligned16(v) && tf_aligned16(out) && tf_aligned16(ws),
            TF_ERR_ALIGN, "tf_ext_attn_fwd: tensors not 16-byte aligned");
     TF_ARG(ws_bytes >= tf_ext_attn_workspace_bytes(K, S, H, Dh, dtype), TF_ERR_WORKSPACE,
@@ -1315,7 +1322,25 @@ extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void
     TF_ARG(p.part != (TF_ATTN_BANK_ONLY | TF_ATTN_SOURCE_ONLY), TF_ERR_SHAPE,
            "tf_ext_attn_fwd: TF_ATTN_BANK_ONLY and TF_ATTN_SOURCE_ONLY exclude each other");
     p.ld = ld;
+    p.q_bs = strides[0];
+    p.q_fs = strides[1];
+    p.k_bs = strides[2];
+    p.k_fs = strides[3];
+    p.v_bs = strides[4];
+    p.v_fs = strides[5];
+    p.o_bs = strides[6];
+    p.o_fs = strides[7];
     p.c = (float)((double)scale * 1.4426950408889634);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return dtype == TF_BF16 ? dispatch_dh<BF16>(Dh, p, v, st) : dispatch_dh<F16>(Dh, p, v, st);
+}
+
+extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void* out, int K, int Kq, int q_frame0,
+                               int S, int H, int Dh, int64_t ld, float scale, int inject, int dtype, void* ws,
+                               size_t ws_bytes, void* stream) {
+    // dense [3, frames, S, ld] tensors; out [3, Kq, S, H*Dh]
+    const int64_t fs = (int64_t)S * ld, ofs = (int64_t)S * H * Dh;
+    const int64_t strides[8] = {Kq * fs, fs, K * fs, fs, K * fs, fs, Kq * ofs, ofs};
+    return tf_ext_attn_fwd_strided(q, k, v, out, K, Kq, q_frame0, S, H, Dh, ld, strides, scale, inject, dtype, ws,
+                                   ws_bytes, stream);
 }

@@ -1,5 +1,6 @@
 """Torch-tensor wrappers over the C ABI.  PyTorch supplies device memory and the
 current HIP stream; all arithmetic happens in the HIP kernels.  No fallbacks."""
+import ctypes
 import os
 from typing import Optional, Sequence
 
@@ -123,6 +124,91 @@ def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scal
     _launch(dev, "tf_ext_attn_fwd", lib.tf_ext_attn_fwd, q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
             K, Kq, int(q_frame0), S, heads, dh, ld, float(scale), flags, dt, ws.data_ptr(), ws.numel())
     return out
+
+
+def _view_base(t: torch.Tensor, b0: int, S: int, what: str):
+    """(base pointer such that branch b lives at base + b*branch_stride, branch stride, frame stride, token stride)
+    of a 4-D view [branches b0.., frames, S, D]."""
+    if t.dim() != 4 or t.shape[2] != S or t.stride(3) != 1:
+        raise ValueError(f"ext_attn_views: {what} must be a [branches, frames, S, D] view with a contiguous last dim")
+    bs = t.stride(0) if t.shape[0] > 1 else 0
+    return t.data_ptr() - b0 * bs * t.element_size(), bs, t.stride(1), t.stride(2)
+
+
+def ext_attn_views(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, heads: int, scale: float,
+                   inject: bool, part: str = "all", branch0=(0, 0, 0, 0), q_frame0: int = 0,
+                   fold_scale: Optional[bool] = None) -> torch.Tensor:
+    """`ext_attn` on strided 4-D views [branches, frames, S, D] (tf_ext_attn_fwd_strided): q, k, v are read where
+    a collective left them and `out` is written where the next one sends from -- no re-layout copies.  Each view
+    holds the branches `branch0[i] ..` of its tensor (q, k, v, out in that order; e.g. a bank-only call passes the
+    uncond/cond slabs with branch0 = 1, and under injection the single source slab of q and k with branch0 = 0).
+    Branch and frame strides are free, the token stride must be the same for q, k, v and dense (= D) for out."""
+    dev = _need_gpu(q, k, v, out)
+    lib = _lib.load()
+    S, D = k.shape[2], k.shape[3]
+    K, Kq, dh = k.shape[1], q.shape[1], D // heads
+    dt = _DT.get(q.dtype)
+    if dt is None or dt == _lib.TF_F32 or k.dtype != q.dtype or v.dtype != q.dtype or D % heads:
+        raise TypeError("ext_attn_views: q/k/v must share dtype bf16 or f16")
+    qp, q_bs, q_fs, ld = _view_base(q, branch0[0], S, "q")
+    kp, k_bs, k_fs, ld_k = _view_base(k, branch0[1], S, "k")
+    vp, v_bs, v_fs, ld_v = _view_base(v, branch0[2], S, "v")
+    op, o_bs, o_fs, ld_o = _view_base(out, branch0[3], S, "out")
+    if ld_k != ld or ld_v != ld or ld_o != D or out.shape[1] != Kq or v.shape[1] != K:
+        raise ValueError("ext_attn_views: q, k, v need one token stride, out a dense one; frames of v = frames of k")
+    if out.dtype not in (q.dtype, torch.float32):
+        raise TypeError("ext_attn_views: out dtype")
+    flags = (1 if inject else 0) | (_lib.TF_ATTN_FOLD_SCALE if (FOLD_SCALE if fold_scale is None else fold_scale) else 0)
+    flags |= {"all": 0, "bank": _lib.TF_ATTN_BANK_ONLY, "source": _lib.TF_ATTN_SOURCE_ONLY}[part]
+    if NO_SPLIT:
+        flags |= _lib.TF_ATTN_NO_SPLIT
+    if out.dtype == torch.float32:
+        flags |= _lib.TF_ATTN_OUT_F32
+    key = (K, S, heads, dh, dt)
+    nbytes = _attn_ws_bytes.get(key)
+    if nbytes is None:
+        nbytes = _attn_ws_bytes[key] = lib.tf_ext_attn_workspace_bytes(K, S, heads, dh, dt)
+    ws = _workspace(nbytes, q.device)
+    strides = (ctypes.c_int64 * 8)(q_bs, q_fs, k_bs, k_fs, v_bs, v_fs, o_bs, o_fs)
+    _launch(dev, "tf_ext_attn_fwd_strided", lib.tf_ext_attn_fwd_strided, qp, kp, vp, op, K, Kq, int(q_frame0), S, heads,
+            dh, ld, ctypes.cast(strides, ctypes.c_void_p), float(scale), flags, dt, ws.data_ptr(), ws.numel())
+    return out
+
+
+def head_pack(slabs: Sequence[torch.Tensor], W: int) -> torch.Tensor:
+    """slabs: ns <= 6 tensors [Kl, S, D] (frame stride free, rows dense-strided, same dtype) -> the all-to-all send
+    buffer [W, Kl, ns, S, D // W]: head group w of every slab, frame-major (tf_head_pack, one launch)."""
+    dev = _need_gpu(*slabs)
+    lib = _lib.load()
+    Kl, S, D = slabs[0].shape
+    ns, hd = len(slabs), D // W
+    ld = slabs[0].stride(1)
+    if D % W or any(t.shape != (Kl, S, D) or t.stride(2) != 1 or t.stride(1) != ld or t.dtype != slabs[0].dtype
+                    for t in slabs):
+        raise ValueError("head_pack: slabs must be [Kl, S, D] views sharing dtype and token stride, D divisible by W")
+    send = torch.empty(W, Kl, ns, S, hd, dtype=slabs[0].dtype, device=slabs[0].device)
+    ptrs = (ctypes.c_void_p * ns)(*[t.data_ptr() for t in slabs])
+    fs = (ctypes.c_int64 * ns)(*[t.stride(0) for t in slabs])
+    _launch(dev, "tf_head_pack", lib.tf_head_pack, ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(fs, ctypes.c_void_p),
+            ns, send.data_ptr(), W, Kl, S, hd, ld, slabs[0].element_size())
+    return send
+
+
+def head_unpack(recv: torch.Tensor, dsts: Sequence[torch.Tensor]) -> None:
+    """recv [W, Kl, nb, S, hd] (what the second all-to-all delivers) -> dsts[b][f, s, w*hd:(w+1)*hd], nb tensors
+    [Kl, S, W*hd] (tf_head_unpack, one launch)."""
+    dev = _need_gpu(recv, *dsts)
+    lib = _lib.load()
+    W, Kl, nb, S, hd = recv.shape
+    ld = dsts[0].stride(1)
+    if (len(dsts) != nb or not recv.is_contiguous()
+            or any(t.shape != (Kl, S, W * hd) or t.stride(2) != 1 or t.stride(1) != ld or t.dtype != recv.dtype
+                   for t in dsts)):
+        raise ValueError("head_unpack: bad arguments")
+    ptrs = (ctypes.c_void_p * nb)(*[t.data_ptr() for t in dsts])
+    fs = (ctypes.c_int64 * nb)(*[t.stride(0) for t in dsts])
+    _launch(dev, "tf_head_unpack", lib.tf_head_unpack, recv.data_ptr(), ctypes.cast(ptrs, ctypes.c_void_p),
+            ctypes.cast(fs, ctypes.c_void_p), nb, W, Kl, S, hd, ld, recv.element_size())
 
 
 def pivot_inv_norm(piv: torch.Tensor) -> torch.Tensor:

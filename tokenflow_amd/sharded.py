@@ -128,26 +128,33 @@ class FrameShard:
         return ops.ext_attn(q_local, kb, vb, heads, scale, inject, q_frame0=self.kf0)
 
     def _pivotal_heads(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool):
+        """Frames <-> heads re-sharding.  Launches per block on this rank: ONE pack kernel, the source-branch
+        attention (overlaps the first all-to-all), the bank attention reading the received buffer IN PLACE and
+        writing the second all-to-all's send buffer IN PLACE (strided views, no re-layout copies), ONE unpack
+        kernel.  Buffers are laid out for the collectives: what a rank sends to peer w is one contiguous
+        [Kl, slabs, S, D/W] piece, so what arrives is [K (global frame order), slabs, S, D/W] whatever the run
+        lengths."""
         W, Kl, K = self.world, self.Kl, self.K
         B, S, D = q_local.shape
         if heads % W:
             raise ValueError(f"{heads} heads do not divide over {W} ranks")
         hd, dev, dt = D // W, q_local.device, q_local.dtype
-        q3, k3, v3 = (t.contiguous().view(3, Kl, S, W, hd) for t in (q_local, k_local, v_local))
+
+        def frames(t):     # [3*Kl, S, D] (token stride free) -> [3, Kl, S, D] view
+            if t.stride(2) != 1 or t.stride(0) != S * t.stride(1):
+                t = t.contiguous()
+            return t.view(3, Kl, S, D) if t.is_contiguous() else t.unflatten(0, (3, Kl))
+        q3, k3, v3 = frames(q_local), frames(k_local), frames(v_local)
+        if not (q3.stride(2) == k3.stride(2) == v3.stride(2)):      # one token stride for the pack kernel
+            q3, k3, v3 = (t.contiguous() for t in (q3, k3, v3))
         even = self.even
-        # ---- pack, frame-major: send[w, f] = head group w of every slab of local keyframe f that the bank
-        #      branches read.  The ranks' runs are contiguous and in rank order, so what arrives is already
-        #      [K (global frame), ns, S, hd] whatever the run lengths.
-        ns = 4 if inject else 6
-        send = torch.empty(W, Kl, ns, S, hd, dtype=dt, device=dev)
+        # ---- pack: head group w of every slab the bank branches read, frame-major, slab order [q.., k.., v..]
         if inject:       # source q, k (what uncond and cond use, 124-130) and the two value banks
-            send[:, :, 0].copy_(q3[0].permute(2, 0, 1, 3))
-            send[:, :, 1].copy_(k3[0].permute(2, 0, 1, 3))
-            send[:, :, 2:4].copy_(v3[1:3].permute(3, 1, 0, 2, 4))
+            slabs = [q3[0], k3[0], v3[1], v3[2]]
         else:
-            sv = send.view(W, Kl, 3, 2, S, hd)
-            for t, x in enumerate((q3, k3, v3)):
-                sv[:, :, t].copy_(x[1:3].permute(3, 1, 0, 2, 4))
+            slabs = [q3[1], q3[2], k3[1], k3[2], v3[1], v3[2]]
+        ns = len(slabs)
+        send = ops.head_pack(slabs, W)                                  # [W, Kl, ns, S, hd]
         recv = torch.empty(K, ns, S, hd, dtype=dt, device=dev)
         work = _all_to_all(recv.view(K, -1), send.view(W * Kl, -1), self.group,
                            None if even else self.counts, None if even else [Kl] * W, async_op=True)
@@ -155,22 +162,19 @@ class FrameShard:
         out = torch.empty(3, Kl, S, D, dtype=dt, device=dev)
         ops.ext_attn(q_local, k_local, v_local, heads, scale, inject, out=out.view(3 * Kl, S, D), part="source")
         work.wait()
-        # ---- unpack into the [3,K,S,hd] q / k / v the kernel reads; slabs it does not read stay unset
-        bank = torch.empty(3, 3, K, S, hd, dtype=dt, device=dev)     # [q|k|v][branch][frame]
+        # ---- bank branches on this rank's head group, all K frames: read `recv`, write `send2`, both in place
+        rp = recv.permute(1, 0, 2, 3)                                   # [ns, K, S, hd] view
+        send2 = torch.empty(K, 2, S, hd, dtype=dt, device=dev)          # [frame][uncond|cond]: rows of rank w's run -> w
+        o4 = send2.permute(1, 0, 2, 3)                                  # [2, K, S, hd] view = branches 1, 2
         if inject:
-            bank[0, 0].copy_(recv[:, 0])
-            bank[1, 0].copy_(recv[:, 1])
-            bank[2, 1:3].copy_(recv[:, 2:4].permute(1, 0, 2, 3))
+            ops.ext_attn_views(rp[0:1], rp[1:2], rp[2:4], o4, heads // W, scale, True, "bank", branch0=(0, 0, 1, 1))
         else:
-            bank[:, 1:3].copy_(recv.view(K, 3, 2, S, hd).permute(1, 2, 0, 3, 4))
-        oh = ops.ext_attn(bank[0].view(3 * K, S, hd), bank[1].view(3 * K, S, hd), bank[2].view(3 * K, S, hd),
-                          heads // W, scale, inject, part="bank")
-        # ---- outputs back to the frame owners, frame-major again: rows of rank w's run go to rank w
-        send2 = oh.view(3, K, S, hd)[1:3].permute(1, 0, 2, 3).contiguous()          # [K, 2, S, hd]
-        recv2 = torch.empty(W, Kl, 2, S, hd, dtype=dt, device=dev)                   # [head group, my frames]
+            ops.ext_attn_views(rp[0:2], rp[2:4], rp[4:6], o4, heads // W, scale, False, "bank", branch0=(1, 1, 1, 1))
+        # ---- outputs back to the frame owners
+        recv2 = torch.empty(W, Kl, 2, S, hd, dtype=dt, device=dev)      # [head group][my frames][uncond|cond]
         _all_to_all(recv2.view(W * Kl, -1), send2.view(K, -1), self.group,
                     None if even else [Kl] * W, None if even else self.counts)
-        out.view(3, Kl, S, W, hd)[1:3].copy_(recv2.permute(2, 1, 3, 0, 4))
+        ops.head_unpack(recv2, [out[1], out[2]])
         return out.view(3 * Kl, S, D)
 
     # ------------------------------------------------------------------ halo for propagation
@@ -178,33 +182,60 @@ class FrameShard:
         """pivots_local [Kl,S,D], inv_local [Kl,S], kf_out_local [3*Kl,S,D] (this rank's keyframes).
         Returns the same three with ONE extra leading keyframe slot = the previous rank's last
         keyframe (unset and unread on rank 0: global chunk 0 matches a single keyframe, 331-333)."""
-        Kl = self.Kl
+        h = self.halo_start(pivots_local, inv_local)
+        return self.halo_finish(h, kf_out_local)
+
+    def halo_start(self, pivots_local: torch.Tensor, inv_local: torch.Tensor):
+        """First half of the halo exchange: the pivot features and inverse norms of the last local keyframe go to
+        rank r+1.  They exist as soon as norm1 has run, BEFORE the attention, so this is issued first and travels
+        under the attention; `halo_finish` then sends the attention output."""
         if self.world == 1:
-            return pivots_local, inv_local, kf_out_local      # no halo slot: ids are [c, c-1] directly
+            return (pivots_local, inv_local, None)
+        Kl = self.Kl
         _, S, D = pivots_local.shape
         # slot 0 = the left neighbour's last keyframe; on rank 0 it stays unset and is never read
-        # (global chunk 0 matches keyframe 0 alone)
         piv = torch.empty(Kl + 1, S, D, dtype=pivots_local.dtype, device=pivots_local.device)
         inv = torch.empty(Kl + 1, S, dtype=inv_local.dtype, device=inv_local.device)
-        kfo = torch.empty(3, Kl + 1, S, D, dtype=kf_out_local.dtype, device=kf_out_local.device)
-        kf3 = kf_out_local.view(3, Kl, S, D)
         piv[1:].copy_(pivots_local)
         inv[1:].copy_(inv_local)
+        reqs = self._p2p([pivots_local[-1], inv_local[-1]], [piv[0], inv[0]])
+        return (piv, inv, reqs)
+
+    def halo_finish(self, handle, kf_out_local: torch.Tensor, wait: bool = True):
+        """Second half: the attention output of the last local keyframe to rank r+1.  wait=False returns the
+        pending requests as a 4th element (call `halo_wait`): the propagation of the local chunks 1.. does not read
+        the halo slot and can be issued before."""
+        piv, inv, reqs = handle
+        if self.world == 1:
+            return (piv, inv, kf_out_local) if wait else (piv, inv, kf_out_local, [])
+        Kl = self.Kl
+        S, D = kf_out_local.shape[1:]
+        kf3 = kf_out_local.view(3, Kl, S, D)
+        kfo = torch.empty(3, Kl + 1, S, D, dtype=kf_out_local.dtype, device=kf_out_local.device)
         kfo[:, 1:].copy_(kf3)
-        # one grouped point-to-point exchange, no staging copies: every message is a contiguous view
-        # (the attention output travels as one message per branch)
+        # no staging copies: every message is a contiguous view (the attention output travels as one message per branch)
+        reqs = list(reqs) + self._p2p([kf3[0, -1], kf3[1, -1], kf3[2, -1]], [kfo[0, 0], kfo[1, 0], kfo[2, 0]])
+        res = (piv, inv, kfo.view(3 * (Kl + 1), S, D))
+        if not wait:
+            return res + (reqs,)
+        self.halo_wait(reqs)
+        return res
+
+    @staticmethod
+    def halo_wait(reqs):
+        for r in reqs:
+            r.wait()
+
+    def _p2p(self, send_tensors, recv_tensors):
+        """One grouped point-to-point exchange: `send_tensors` to rank r+1, `recv_tensors` from rank r-1."""
         opsl = []
         if self.rank + 1 < self.world:
             peer = self._peer(self.rank + 1)
-            opsl += [dist.P2POp(dist.isend, t, peer, self.group)
-                     for t in (pivots_local[-1], inv_local[-1], kf3[0, -1], kf3[1, -1], kf3[2, -1])]
+            opsl += [dist.P2POp(dist.isend, t, peer, self.group) for t in send_tensors]
         if self.rank > 0:
             peer = self._peer(self.rank - 1)
-            opsl += [dist.P2POp(dist.irecv, t, peer, self.group)
-                     for t in (piv[0], inv[0], kfo[0, 0], kfo[1, 0], kfo[2, 0])]
-        for req in (dist.batch_isend_irecv(opsl) if opsl else []):
-            req.wait()
-        return piv, inv, kfo.view(3 * (Kl + 1), S, D)
+            opsl += [dist.P2POp(dist.irecv, t, peer, self.group) for t in recv_tensors]
+        return dist.batch_isend_irecv(opsl) if opsl else []
 
     def _peer(self, group_rank: int) -> int:
         return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
@@ -223,10 +254,23 @@ class FrameShard:
                              out_dtype)
 
     def propagate_all(self, tgt_all: torch.Tensor, residual_all: torch.Tensor, piv_ext, inv_ext, kf_out_ext,
-                      w: torch.Tensor, n: int, out_dtype: torch.dtype = torch.float32):
-        """ALL local chunks in one call (tf_nn_gather_blend_chunks): tgt_all [Kl*n*S, D] chunk-major, residual_all
+                      w: torch.Tensor, n: int, out_dtype: torch.dtype = torch.float32, halo_reqs=None):
+        """ALL local chunks (tf_nn_gather_blend_chunks): tgt_all [Kl*n*S, D] chunk-major, residual_all
         [3*Kl*n, S, D] (frames chunk-major inside each branch).  Same results as Kl calls of `propagate`, bit for
-        bit; the one-keyframe chunk 0 of the video (rank 0) is rounded to the dtype its own call would produce."""
+        bit; the one-keyframe chunk 0 of the video (rank 0) is rounded to the dtype its own call would produce.
+        halo_reqs (from `halo_finish(wait=False)`): the local chunks 1.. read no halo slot and are issued FIRST,
+        the first local chunk after the halo has landed; returns (first chunk [3n,S,D], rest [3(Kl-1)n,S,D] or None)."""
         o = 1 if self.world > 1 else 0
-        return ops.propagate_chunks(tgt_all, piv_ext, inv_ext, kf_out_ext, w, n, self.Kl, o, self.kf0 == 0,
-                                    residual_all, out_dtype)
+        if halo_reqs is None:
+            return ops.propagate_chunks(tgt_all, piv_ext, inv_ext, kf_out_ext, w, n, self.Kl, o, self.kf0 == 0,
+                                        residual_all, out_dtype)
+        Kl, S, D = self.Kl, piv_ext.shape[1], piv_ext.shape[2]
+        nS = n * S
+        res = residual_all.view(3, Kl, n, S, D)
+        rest = None
+        if Kl > 1:
+            rest = ops.propagate_chunks(tgt_all[nS:], piv_ext, inv_ext, kf_out_ext, w, n, Kl - 1, o + 1, False,
+                                        res[:, 1:].reshape(3 * (Kl - 1) * n, S, D), out_dtype)
+        self.halo_wait(halo_reqs)
+        first = self.propagate(0, tgt_all[:nS], res[:, 0].reshape(3 * n, S, D), piv_ext, inv_ext, kf_out_ext, w, n)
+        return first, rest

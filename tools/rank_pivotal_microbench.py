@@ -39,6 +39,15 @@ g = torch.Generator(device="cuda").manual_seed(0)
 for lvl, (S, D, h) in enumerate(cfg.levels):
     q, k, v = (torch.randn(3 * sh.Kl, S, D, generator=g, device="cuda").bfloat16() for _ in range(3))
     for inj in (False, True):
-        avg, mn = time_it(lambda: sh._pivotal_heads(q, k, v, h, (D // h) ** -0.5, inj), reps=20, warm=3)
-        print(f"rank 0 of {W}, level {lvl} (S={S}, D={D}) inject={int(inj)}: pivotal pass without the wire {avg * 1e3:7.1f} us",
-              flush=True)
+        fn = lambda: sh._pivotal_heads(q, k, v, h, (D // h) ** -0.5, inj)
+        avg, mn = time_it(fn, reps=20, warm=3)
+        # host-side issue time: how long the CPU needs to enqueue the pass (GPU idle at the start, no sync inside)
+        import time
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            fn()
+        host = (time.perf_counter() - t0) / 20
+        torch.cuda.synchronize()
+        print(f"rank 0 of {W}, level {lvl} (S={S}, D={D}) inject={int(inj)}: pivotal pass without the wire "
+              f"GPU {avg * 1e3:7.1f} us, host issue {host * 1e6:7.1f} us", flush=True)
