@@ -84,11 +84,12 @@ class FakeOps:
             out[b - branch0[3]] = res[b]
         return out
 
-    def head_pack(self, slabs, W):
+    def head_pack(self, slabs, W, out=None):
         Kl, S, D = slabs[0].shape
         hd = D // W
         st = torch.stack([t.reshape(Kl, S, W, hd) for t in slabs], dim=1)     # [Kl, ns, S, W, hd]
-        return st.permute(3, 0, 1, 2, 4).contiguous()                          # [W, Kl, ns, S, hd]
+        res = st.permute(3, 0, 1, 2, 4).contiguous()                           # [W, Kl, ns, S, hd]
+        return res if out is None else out.copy_(res)
 
     def head_unpack(self, recv, dsts):
         W, Kl, nb, S, hd = recv.shape

@@ -231,13 +231,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     // form: it is set from the first tile's maximum and moved only when a tile maximum exceeds it by more than
     // FOLD_T binades; P = exp2((s - m_run) c) may then exceed 1 (<= 2^FOLD_T), numerator and denominator see the
     // same P.  Saves the 16 v_max3 + permlane of most tiles and most O rescales.
-#ifndef TF_TUNE_BOUND_EXACT
-#define TF_TUNE_BOUND_EXACT 1     // A/B knobs of the round-2 experiments (tools/build_variants.sh); defaults = shipped form
-#endif
-#ifndef TF_TUNE_SCALAR_FMA
-#define TF_TUNE_SCALAR_FMA 0
-#endif
-    constexpr bool BOUND = DH == 40 && (FOLD || TF_TUNE_BOUND_EXACT);
+    //   Measured (round 2, cfg2 level 0, fp32 scaling): 4.25 -> 4.03 ms with the bound; the folded form is 3.58 ms.
+    constexpr bool BOUND = DH == 40;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     auto sK = [&](int buf) { return reinterpret_cast<E*>(smem) + buf * BUF_ELEMS; };
@@ -562,11 +557,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
                     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                         for (int r = 0; r < 16; r += 2) {
-#if TF_TUNE_SCALAR_FMA
-                            const float x[2] = {fmaf(s[qi][kt][r], c, -mc), fmaf(s[qi][kt][r + 1], c, -mc)};
-#else
-                            const f32x2 x = f32x2{s[qi][kt][r], s[qi][kt][r + 1]} * c2 - mc2;  // v_pk_fma_f32
-#endif
+                            // v_pk_fma_f32: 16 instead of 32 VALU per tile (two scalar v_fma measured +16 % kernel time)
+                            const f32x2 x = f32x2{s[qi][kt][r], s[qi][kt][r + 1]} * c2 - mc2;
                             const float p0 = __builtin_amdgcn_exp2f(x[0]);
                             const float p1 = __builtin_amdgcn_exp2f(x[1]);
                             if constexpr (!ONES) lsum += p0 + p1;

@@ -349,9 +349,18 @@ def _fused_norm_dtype(mod: torch.nn.Module, x: torch.Tensor):
     return None
 
 
-def _block_norm(mod: torch.nn.Module, x: torch.Tensor, want_inv_norm: bool = False):
+# Which LayerNorms of a block go through `ops.layer_norm`:  "all" (default) = norm1 -- the producer of the attention
+# input, the NN-search rows and the pivots' inverse norms (row f2 of SURVEY.md section 8) -- and also norm2 / norm3,
+# whose only consumers are Linear layers (attn2.to_q, the feed-forward): under autocast torch evaluates layer_norm
+# in fp32 and the Linear rounds its input to 16 bit, so the kernel's single rounding of the fp32 result IS the value
+# the reference's Linear sees (pinned by tests/test_fullsize_gpu.py::test_fused_layer_norm_is_the_autocast_value);
+# "norm1" = only norm1; "none" = always the modules.
+FUSE_NORMS = os.environ.get("TOKENFLOW_FUSED_NORMS", "all")
+
+
+def _block_norm(mod: torch.nn.Module, x: torch.Tensor, want_inv_norm: bool = False, which: str = "norm1"):
     """(LayerNorm(x), 1/||row|| or None) through the fused kernel when it applies, else the module itself."""
-    dt = _fused_norm_dtype(mod, x)
+    dt = _fused_norm_dtype(mod, x) if (FUSE_NORMS == "all" or FUSE_NORMS == which) else None
     if dt is None:
         return mod(x), None
     return ops.layer_norm(x, mod.weight, mod.bias, mod.eps, dt, want_inv_norm)
@@ -452,14 +461,17 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
 
             if self.attn2 is not None:
                 norm_hidden_states = (
-                    self.norm2(hidden_states, timestep) if self.use_ada_layer_norm else self.norm2(hidden_states))
+                    self.norm2(hidden_states, timestep) if self.use_ada_layer_norm
+                    else _block_norm(self.norm2, hidden_states, which="norm2")[0])
                 attn_output = self.attn2(norm_hidden_states, encoder_hidden_states=encoder_hidden_states,
                                          attention_mask=encoder_attention_mask, **cross_attention_kwargs)
                 hidden_states = attn_output + hidden_states
 
-            norm_hidden_states = self.norm3(hidden_states)
-            if self.use_ada_layer_norm_zero:
+            if self.use_ada_layer_norm_zero:    # the modulation consumes the fp32 norm output: keep the module
+                norm_hidden_states = self.norm3(hidden_states)
                 norm_hidden_states = norm_hidden_states * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
+            else:
+                norm_hidden_states = _block_norm(self.norm3, hidden_states, which="norm3")[0]
             ff_output = self.ff(norm_hidden_states)
             if self.use_ada_layer_norm_zero:
                 ff_output = gate_mlp.unsqueeze(1) * ff_output

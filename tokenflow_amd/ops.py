@@ -175,7 +175,7 @@ def ext_attn_views(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch
     return out
 
 
-def head_pack(slabs: Sequence[torch.Tensor], W: int) -> torch.Tensor:
+def head_pack(slabs: Sequence[torch.Tensor], W: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """slabs: ns <= 6 tensors [Kl, S, D] (frame stride free, rows dense-strided, same dtype) -> the all-to-all send
     buffer [W, Kl, ns, S, D // W]: head group w of every slab, frame-major (tf_head_pack, one launch)."""
     dev = _need_gpu(*slabs)
@@ -186,7 +186,9 @@ def head_pack(slabs: Sequence[torch.Tensor], W: int) -> torch.Tensor:
     if D % W or any(t.shape != (Kl, S, D) or t.stride(2) != 1 or t.stride(1) != ld or t.dtype != slabs[0].dtype
                     for t in slabs):
         raise ValueError("head_pack: slabs must be [Kl, S, D] views sharing dtype and token stride, D divisible by W")
-    send = torch.empty(W, Kl, ns, S, hd, dtype=slabs[0].dtype, device=slabs[0].device)
+    if out is None:
+        out = torch.empty(W, Kl, ns, S, hd, dtype=slabs[0].dtype, device=slabs[0].device)
+    send = out
     ptrs = (ctypes.c_void_p * ns)(*[t.data_ptr() for t in slabs])
     fs = (ctypes.c_int64 * ns)(*[t.stride(0) for t in slabs])
     _launch(dev, "tf_head_pack", lib.tf_head_pack, ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(fs, ctypes.c_void_p),

@@ -78,6 +78,20 @@ class FrameShard:
         self.even = K % self.world == 0
         self.Kl = self.counts[self.rank]       # local keyframes == local chunks
         self.kf0 = self.offsets[self.rank]     # first global keyframe / chunk of this rank
+        self._bufs = {}                        # exchange buffers by (tag, shape, dtype, device): reused block after block
+
+    def _buf(self, tag, shape, dtype, device):
+        """Receive / send scratch of the exchanges.  Every use is complete (the collective waited for, the consumer
+        kernel enqueued on the same stream) before the next block touches the buffer again, so one buffer per shape
+        serves all blocks -- and saves an allocator round trip per buffer and block on the host."""
+        key = (tag, tuple(shape), dtype, device)
+        b = getattr(self, "_bufs", None)
+        if b is None:
+            b = self._bufs = {}
+        t = b.get(key)
+        if t is None:
+            t = b[key] = torch.empty(shape, dtype=dtype, device=device)
+        return t
 
     # ------------------------------------------------------------------ pivotal pass
     def gather_bank(self, k_local: torch.Tensor, v_local: torch.Tensor, inject: bool
@@ -154,8 +168,8 @@ class FrameShard:
         else:
             slabs = [q3[1], q3[2], k3[1], k3[2], v3[1], v3[2]]
         ns = len(slabs)
-        send = ops.head_pack(slabs, W)                                  # [W, Kl, ns, S, hd]
-        recv = torch.empty(K, ns, S, hd, dtype=dt, device=dev)
+        send = ops.head_pack(slabs, W, out=self._buf("send", (W, Kl, ns, S, hd), dt, dev))
+        recv = self._buf("recv", (K, ns, S, hd), dt, dev)
         work = _all_to_all(recv.view(K, -1), send.view(W * Kl, -1), self.group,
                            None if even else self.counts, None if even else [Kl] * W, async_op=True)
         # ---- source branch: own-frame keys, all heads, stays local (overlaps the exchange)
@@ -164,14 +178,14 @@ class FrameShard:
         work.wait()
         # ---- bank branches on this rank's head group, all K frames: read `recv`, write `send2`, both in place
         rp = recv.permute(1, 0, 2, 3)                                   # [ns, K, S, hd] view
-        send2 = torch.empty(K, 2, S, hd, dtype=dt, device=dev)          # [frame][uncond|cond]: rows of rank w's run -> w
+        send2 = self._buf("send2", (K, 2, S, hd), dt, dev)            # [frame][uncond|cond]: rows of rank w's run -> w
         o4 = send2.permute(1, 0, 2, 3)                                  # [2, K, S, hd] view = branches 1, 2
         if inject:
             ops.ext_attn_views(rp[0:1], rp[1:2], rp[2:4], o4, heads // W, scale, True, "bank", branch0=(0, 0, 1, 1))
         else:
             ops.ext_attn_views(rp[0:2], rp[2:4], rp[4:6], o4, heads // W, scale, False, "bank", branch0=(1, 1, 1, 1))
         # ---- outputs back to the frame owners
-        recv2 = torch.empty(W, Kl, 2, S, hd, dtype=dt, device=dev)      # [head group][my frames][uncond|cond]
+        recv2 = self._buf("recv2", (W, Kl, 2, S, hd), dt, dev)        # [head group][my frames][uncond|cond]
         _all_to_all(recv2.view(W * Kl, -1), send2.view(K, -1), self.group,
                     None if even else [Kl] * W, None if even else self.counts)
         ops.head_unpack(recv2, [out[1], out[2]])
