@@ -152,7 +152,7 @@ def test_fused_layer_norm_is_the_autocast_value(rows, D, in_dtype):
     """Pin for fusing the block's LayerNorms: under autocast torch evaluates layer_norm in fp32 and the Linear that
     consumes it rounds its input to bf16 -- that rounded tensor is what `ops.layer_norm(..., bf16)` must produce.
     Equal everywhere except where the two fp32 evaluations (different summation order) fall on opposite sides of
-    a bf16 rounding boundary: at most one bf16 ulp apart, on < 0.05 % of the elements."""
+    a bf16 rounding boundary: at most one bf16 ulp (or the fp32 noise floor, 4e-6) apart, on < 0.05 % of the elements."""
     ops = _ops()
     g = torch.Generator(device="cuda").manual_seed(D)
     x = (torch.randn(rows, D, generator=g, device="cuda") * 2 + 0.3).to(in_dtype)
@@ -166,8 +166,10 @@ def test_fused_layer_norm_is_the_autocast_value(rows, D, in_dtype):
         want = ref32.to(torch.bfloat16)                           # what the next Linear's autocast cast produces
         got, _ = ops.layer_norm(x, ln.weight, ln.bias, ln.eps, torch.bfloat16)
     diff = (got.float() - want.float()).abs()
-    ulp = 2.0 ** -7 * want.float().abs().clamp(min=2.0 ** -126)   # one bf16 ulp is <= 2^-7 |x|
-    assert bool((diff <= ulp).all())
+    # one bf16 ulp (<= 2^-7 |x|); where normalised term and bias cancel to |y| << 1 the two fp32 evaluations differ by
+    # their ABSOLUTE rounding noise (~1e-6 at these magnitudes), which can be many ulps of the tiny result
+    ulp = 2.0 ** -7 * want.float().abs() + 4e-6
+    assert bool((diff <= ulp).all()), float((diff - ulp).max())
     assert float((diff > 0).float().mean()) < 5e-4
 
 

@@ -449,9 +449,9 @@ static NnPlan nn_plan(int64_t n_tgt, int S, int D, int P, int C = 1) {
     pl.panels = (n_tgt + tn - 1) / tn;
     const int n_tiles = (S + tm - 1) / tm;
     int splits = 1;
-    // a multi-chunk launch keeps >= 4 pivot tiles per split: below that the per-workgroup fixed cost (target fragments,
-    // partial results, their merge) outweighs the finer tail (cfg1 level 0: 41.8 us at 4 tiles / split, 72 us at 1)
-    const int min_tiles = C > 1 ? 4 : 1;
+    // a multi-chunk launch keeps >= 128 pivots per split: below that the per-workgroup fixed cost (target fragments,
+    // partial results, their merge) outweighs the finer tail (cfg1 level 0: 41.8 us at 128 pivots / split, 72 us at 32)
+    const int min_tiles = C > 1 ? (128 + tm - 1) / tm : 1;
     while (pl.panels * C * P * splits < nn_min_wgs(C) && splits * 2 <= n_tiles && n_tiles / (splits * 2) >= min_tiles)
         splits *= 2;
     pl.tiles_per_split = (n_tiles + splits - 1) / splits;
