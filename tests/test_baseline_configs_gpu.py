@@ -508,3 +508,54 @@ def test_head_pack_unpack(W, Kl, S, D, dtype):
     ops.head_unpack(recv2, [out[1], out[2]])
     assert torch.equal(out[1:3].view(2, Kl, S, W, hd), recv2.permute(2, 1, 3, 0, 4))
     assert bool((out[0] == 0).all())
+
+
+# ------------------------------------------------------------------------------------------- interleaved Dh = 40 kernel
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("gain", [0.0, 3.0, 12.0])
+def test_ext_attn_interleaved_form_full_oracle(dtype, gain):
+    """ext_attn_il40_kernel (Dh = 40, fp32 scaling, grids of >= 768 workgroups, S % 64 == 0: the cfg2 level-0 form)
+    against the full oracle, K = 4 x S = 2048 x 8 heads.  gain > 0 plants spikes (one strongly aligned key per
+    query, in LATE tiles of the bank): gain 3 keeps the score bound tight enough that no half tile looks at its
+    maximum, gain 12 breaks it so that the deferred shift moves in the middle of the software pipeline -- the
+    half tile whose P.V runs beside that softmax was exponentiated against the OLD shift and must be rescaled
+    exactly once (cdna_hip_programming.md T13 / rule 26).  Both the bank problems (K*S keys) and the source problems."""
+    ops = _ops()
+    K, S, h, d = 4, 2048, 8, 40
+    D = h * d
+    g = torch.Generator().manual_seed(int(gain) + 5)
+    q, k, v = (torch.randn(3 * K, S, D, generator=g) for _ in range(3))
+    if gain:
+        qv, kv = q.view(3 * K, S, h, d), k.view(3 * K, S, h, d)
+        for b in range(3 * K):
+            for s_ in range(0, S, 3):
+                kv[b, (s_ * 5 + 1500) % S] = qv[b, s_] * gain      # lands in tiles 0..31 of a frame, mostly late ones
+    rnd = orc.bf16_round if dtype == torch.bfloat16 else (lambda x: x.half().float())
+    q, k, v = rnd(q), rnd(k), rnd(v)
+    refs = attn_ref(q, k, v, h, d ** -0.5, False, need_sigma=False)
+    dq, dk, dv = (t.to(dtype).cuda() for t in (q, k, v))
+    out = ops.ext_attn(dq, dk, dv, h, d ** -0.5, False)
+    assert bool(torch.isfinite(out.float()).all())
+    assert_attn_close(out, refs, f"interleaved gain={gain} {dtype}", dtype=dtype)
+    o32 = ops.ext_attn(dq, dk, dv, h, d ** -0.5, False, out_dtype=torch.float32)
+    assert torch.equal(o32.to(dtype), out)
+    src = ops.ext_attn(dq, dk, dv, h, d ** -0.5, False, part="source", out=torch.zeros_like(dq))
+    assert torch.equal(src.view(3, -1)[0], out.view(3, -1)[0]) and bool((src.view(3, -1)[1:] == 0).all())
+
+
+def test_ext_attn_interleaved_form_negative_first_tile():
+    """The first tile 158 binades below the rest, at the interleaved kernel's size."""
+    ops = _ops()
+    K, S, h, d = 4, 2048, 8, 40
+    D = h * d
+    g = torch.Generator().manual_seed(9)
+    q, k, v = (torch.randn(3 * K, S, D, generator=g) for _ in range(3))
+    u = torch.nn.functional.normalize(torch.randn(h, d, generator=g), dim=-1)
+    amp = (110.0 * d ** 0.5) ** 0.5
+    q = (amp * u.view(1, 1, h, d) + 0.05 * q.view(3 * K, S, h, d)).reshape(3 * K, S, D)
+    kv = k.view(3 * K, S, h, d)
+    kv[:, :64] = -amp * u.view(1, 1, h, d) + 0.05 * kv[:, :64]
+    q, k, v = (orc.bf16_round(t) for t in (q, kv.reshape(3 * K, S, D), v))
+    out = ops.ext_attn(q.bfloat16().cuda(), k.bfloat16().cuda(), v.bfloat16().cuda(), h, d ** -0.5, False)
+    assert bool(torch.isfinite(out.float()).all())
+    assert_attn_close(out, attn_ref(q, k, v, h, d ** -0.5, False, need_sigma=False), "interleaved, negative first tile")

@@ -1130,6 +1130,336 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Half-tile interleaved variant for Dh = 40, fp32 score scaling (the default).
+//
+// The plain kernel runs QK^T (6 MFMAs) -> softmax (64 VALU) -> P.V (8 MFMAs) of one 64-key tile back to back:
+// inside a wave the matrix pipe idles during the softmax and the VALU during the MFMAs, and the overlap that four
+// independent waves per SIMD provide stops at ~49 % matrix-pipe utilisation.  Here ONE query tile
+// per wave is software-pipelined over 32-key half tiles, so that every stretch of the instruction stream has
+// INDEPENDENT matrix and vector work, issued alternately (one MFMA, ~5 VALU, pinned by sched_barrier(0)):
+//     phase 1 of tile t:  O += V0(t) P0(t)  and  S0(t+1) = K0(t+1) Q   (7 MFMAs)  ||  P1(t)   = exp2(S1(t) c - m c)
+//     phase 2 of tile t:  O += V1(t) P1(t)  and  S1(t+1) = K1(t+1) Q   (7 MFMAs)  ||  P0(t+1) = exp2(S0(t+1) c - m c)
+// Same registers as the plain kernel (the two 32-key score halves were separate accumulators already), same LDS
+// images, K staged one tile earlier (as in the ping-pong kernel): top of iteration t writes K(t+1) and V(t) from
+// registers loaded an iteration before, one barrier, then the two phases.
+// Online softmax with the score bound (BOUND): a half tile looks at its maximum only when the bound does not
+// exclude an overflow; when the shift moves, O -- which by then includes the P.V of the half tile that ran beside
+// the softmax, computed against the OLD shift -- is rescaled at the END of the phase, before any P at the new
+// shift is multiplied in (cdna_hip_programming.md T13: scale everything still at the old maximum exactly once).
+// Scope: S a multiple of 64, no split form, MODE_ALL / MODE_SOURCE problems (the dual-V form has its own kernel).
+template <typename T, int MODE, int MINW>
+__global__ __launch_bounds__(512, MINW) void ext_attn_il40_kernel(AttnParams p) {
+    constexpr int DH = 40;
+    typedef AttnCfg<DH, 64> C;
+    typedef typename T::elem E;
+    typedef typename T::vec8 vec8;
+    typedef typename T::vec4 vec4;
+    constexpr int NT = 512;
+    constexpr int NPK = C::npk(NT), NPV = C::npv(NT);
+    constexpr int BUF_ELEMS = C::K_ELEMS + C::V_ELEMS;
+    constexpr int ONES_R = ((DH % 32) & 3) + 4 * ((DH % 32) >> 3);
+    constexpr float BOUND_T = std::is_same<E, _Float16>::value ? 14.0f : 60.0f;
+    static_assert(NPK == 1 && NPV == 1, "one K piece and one V^T piece per thread");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    auto sK = [&](int buf) { return reinterpret_cast<E*>(smem) + buf * BUF_ELEMS; };
+    auto sV = [&](int buf) { return reinterpret_cast<E*>(smem) + buf * BUF_ELEMS + C::K_ELEMS; };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int hi = lane >> 5;
+    const int l31 = lane & 31;
+    const int K = p.K, Kq = p.Kq, S = p.S, H = p.H;
+
+    const int h = blockIdx.x % H;
+    int u = blockIdx.x / H;
+    int b, f, qt;
+    if constexpr (MODE == MODE_ALL) {
+        const int nbank = 2 * Kq * p.nQT;
+        if (u < nbank) {
+            b = 1 + u / (Kq * p.nQT);
+            u -= (b - 1) * Kq * p.nQT;
+        } else {
+            u -= nbank;
+            b = 0;
+        }
+    } else {
+        b = 0;
+    }
+    f = u / p.nQT;
+    qt = u - f * p.nQT;
+    const int bq = (p.inject && b > 0) ? 0 : b;
+    const int f_lo = b == 0 ? p.q_frame0 + f : 0;
+    const int n_fr = b == 0 ? 1 : K;
+    const int tpf = S >> 6;
+    const int ntiles = n_fr * tpf;
+
+    const E* qg = reinterpret_cast<const E*>(p.q);
+    const E* kg = reinterpret_cast<const E*>(p.k) + bq * p.k_bs + h * DH;
+    const int64_t vt_row = vt_row_stride(K, p.Spad);
+    const E* vg = reinterpret_cast<const E*>(p.vt) + ((int64_t)(b * H + h) * DH) * vt_row;
+
+    // ---- LDS init: zero everything (pads; the V^T rows 41..63), then the denominator row DH of both V^T images
+    for (int id = tid; id < 2 * BUF_ELEMS / 8; id += NT) st16(reinterpret_cast<E*>(smem) + id * 8, u32x4{0, 0, 0, 0});
+    __syncthreads();
+    for (int id = tid; id < 2 * 64; id += NT) sV(id >> 6)[DH * C::VROW + (id & 63)] = (E)1.f;
+
+    // ---- Q fragments
+    const int q_row = qt * 256 + wave * 32 + l31;
+    const bool q_ok = q_row < S;
+    vec8 qf[C::KS];
+    {
+        const E* qp = qg + bq * p.q_bs + f * p.q_fs + (int64_t)(q_ok ? q_row : S - 1) * p.ld + h * DH;
+#pragma unroll
+        for (int t = 0; t < C::KS; ++t) {
+            const int col = 16 * t + 8 * hi;
+            qf[t] = __builtin_bit_cast(vec8, col < DH ? ld16(qp + col) : u32x4{0, 0, 0, 0});
+        }
+    }
+    const float c = p.c;
+    // score bound (log2 units) over every key this problem sees: |q| max|k| c  (see BOUND in ext_attn_kernel)
+    float s_bound;
+    {
+        const int ppf = p.Spad / 64;
+        const float* part = p.knorm2 + ((int64_t)(bq * H + h) * K + f_lo) * ppf;
+        float kn2 = 0.f;
+        for (int i = lane; i < n_fr * ppf; i += 64) kn2 = fmaxf(kn2, part[i]);
+#pragma unroll
+        for (int o_ = 32; o_ > 0; o_ >>= 1) kn2 = fmaxf(kn2, __shfl_xor(kn2, o_));
+        float q2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < C::KS; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q2 = fmaf((float)qf[t][j], (float)qf[t][j], q2);
+        q2 += __shfl_xor(q2, 32);
+        s_bound = __builtin_sqrtf(q2) * __builtin_sqrtf(kn2) * 1.001f * c;
+    }
+
+    // ---- staging: one 16-B piece of K and one of V^T per thread and tile (branch-free, see ext_attn_kernel)
+    u32x4 rk, rv;
+    const int k_id = min(tid, 64 * C::PPR - 1), v_id = min(tid, DH * 8 - 1);
+    const int k_goff = (k_id / C::PPR) * (int)p.ld + (k_id % C::PPR) * 8;
+    const int k_loff = (k_id / C::PPR) * C::KROW + (k_id % C::PPR) * 8;
+    const int v_goff = (v_id >> 3) * (int)vt_row + (v_id & 7) * 8;
+    const int v_loff = (v_id >> 3) * C::VROW + (v_id & 7) * 8;
+    const int v_wrap = p.Spad - (tpf - 1) * 64;
+    const int64_t k_wrap_off = p.k_fs - (int64_t)(tpf - 1) * 64 * p.ld;
+    const E* k_next = kg + f_lo * p.k_fs;
+    const E* v_next = vg + (int64_t)f_lo * p.Spad;
+    int k_tt = 0, v_tt = 0;
+    auto load_k = [&]() {
+        rk = ld16(k_next + k_goff);
+        const bool wrap = k_tt == tpf - 1;
+        k_next += wrap ? k_wrap_off : (int64_t)64 * p.ld;
+        k_tt = wrap ? 0 : k_tt + 1;
+    };
+    auto load_v = [&]() {
+        rv = ld16(v_next + v_goff);
+        const bool wrap = v_tt == tpf - 1;
+        v_next += wrap ? v_wrap : 64;
+        v_tt = wrap ? 0 : v_tt + 1;
+    };
+    auto write_k = [&](int buf) {
+        if (tid < 64 * C::PPR) st16(sK(buf) + k_loff, rk);
+    };
+    auto write_v = [&](int buf) {
+        if (tid < DH * 8) st16(sV(buf) + v_loff, rv);
+    };
+
+    f32x16 o[C::MT], s[2];
+    vec8 pf[2][2];      // P of the two 32-key halves, two 16-key k-steps each
+    float m_run = -INFINITY;   // deferred shift, raw-score units
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[mt][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[kt][ks][j] = (E)0.f;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // decision part of the online softmax of half X: returns alpha (1 = no move) and leaves m_run updated
+    auto sm_decide = [&](auto x_c, bool& move) -> float {
+        constexpr int X = decltype(x_c)::value;
+        move = false;
+        float alpha = 1.f;
+        if (__any(s_bound - m_run * c > BOUND_T)) {
+            float mx = s[X][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[X][r]);
+            mx = max_with_lane_xor32(mx);
+            const bool over = (mx - m_run) * c > BOUND_T;
+            if (__any(over)) {
+                move = true;
+                const float m_new = over ? mx : m_run;
+                alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);   // exp2(-inf) = 0 on the first half tile (O is 0)
+                m_run = m_new;
+            }
+        }
+        return alpha;
+    };
+    auto rescale = [&](float alpha) {
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
+    };
+    // one softmax unit: two scores of half X -> P (8 units per half)
+    auto sm_unit = [&](auto x_c, int un, f32x2 c2, f32x2 mc2) {
+        constexpr int X = decltype(x_c)::value;
+        const int r = un * 2;
+        const f32x2 x = f32x2{s[X][r], s[X][r + 1]} * c2 - mc2;
+        pf[X][r >> 3][r & 7] = (E)__builtin_amdgcn_exp2f(x[0]);
+        pf[X][r >> 3][(r & 7) + 1] = (E)__builtin_amdgcn_exp2f(x[1]);
+    };
+
+    // One phase: the MFMAs of P.V half Hh of the current tile (V^T buffer vbuf) and -- NEXT -- of QK^T half Hh of the
+    // next tile (K buffer kbuf), interleaved in program order with the softmax of half 1 - Hh (SM: there is one).
+    auto phase = [&](auto h_c, auto next_c, auto sm_c, int vbuf, int kbuf) {
+        constexpr int Hh = decltype(h_c)::value;
+        constexpr int X = 1 - Hh;
+        constexpr bool NEXT = decltype(next_c)::value, SM = decltype(sm_c)::value;
+        constexpr int NM = NEXT ? 7 : 4;
+        // MFMA order: never two MFMAs on the same accumulator next to each other
+        //   NEXT: QK k0, PV(m0,ks0), QK k1, PV(m1,ks0), QK k2, PV(m0,ks1), PV(m1,ks1);  else the four PV
+        constexpr int is_pv[7] = {NEXT ? 0 : 1, 1, NEXT ? 0 : 1, 1, 0, 1, 1};
+        constexpr int idx_a[7] = {0, NEXT ? 0 : 1, NEXT ? 1 : 0, 1, 2, 0, 1};   // PV: M-tile;  QK: k-step
+        constexpr int idx_b[7] = {0, 0, NEXT ? 0 : 1, NEXT ? 0 : 1, 0, 1, 1};   // PV: 16-key k-step of the half
+        bool move = false;
+        float alpha = 1.f;
+        f32x2 c2 = {c, c}, mc2 = {0.f, 0.f};
+        if constexpr (SM) {
+            alpha = sm_decide(std::integral_constant<int, X>{}, move);
+            const float mc = m_run * c;
+            mc2 = f32x2{mc, mc};
+        }
+        const E* vbase = sV(vbuf) + l31 * C::VROW + Hh * 32 + 8 * hi;
+        const E* kbase = sK(kbuf) + (Hh * 32 + l31) * C::KROW + 8 * hi;
+        auto frag = [&](int i) -> vec8 {
+            if (is_pv[i]) return __builtin_bit_cast(vec8, ld16(vbase + idx_a[i] * 32 * C::VROW + 16 * idx_b[i]));
+            return __builtin_bit_cast(vec8, ld16(kbase + 16 * idx_a[i]));
+        };
+        constexpr int PF = 2;   // fragment reads run PF steps ahead of their MFMA (3: 132 VGPRs, one workgroup per CU)
+        vec8 fr[NM];
+#pragma unroll
+        for (int i = 0; i < PF && i < NM; ++i) fr[i] = frag(i);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            if (i + PF < NM) fr[i + PF] = frag(i + PF);
+            if (is_pv[i]) {
+                o[idx_a[i]] = T::mfma32(fr[i], pf[Hh][idx_b[i]], o[idx_a[i]]);
+            } else {
+                s[Hh] = T::mfma32(fr[i], qf[idx_a[i]], idx_a[i] == 0 ? zero : s[Hh]);
+            }
+            if constexpr (SM) {
+#pragma unroll
+                for (int un = (i * 8) / NM; un < ((i + 1) * 8) / NM; ++un)
+                    sm_unit(std::integral_constant<int, X>{}, un, c2, mc2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (SM) {
+            // P of half X must exist HERE (keeps the register-only softmax from sinking towards its consumer)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(pf[X][ks]));
+            // the shift moved: O (now including this phase's P.V, computed against the old shift) is rescaled before
+            // any P at the new shift is multiplied in
+            if (move) rescale(alpha);
+        }
+    };
+    typedef std::integral_constant<int, 0> H0;
+    typedef std::integral_constant<int, 1> H1;
+    typedef std::true_type Yes;
+    typedef std::false_type No;
+
+    // ---- prologue: K(0) -> Kbuf[0]; S(0) = K(0) Q; P0(0); registers <- K(1), V(0)
+    load_k();
+    __syncthreads();            // LDS init done before the first staging write
+    write_k(0);
+    if (ntiles > 1) load_k();   // K(1)
+    load_v();                   // V(0)
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const E* krow = sK(0) + (kt * 32 + l31) * C::KROW + 8 * hi;
+#pragma unroll
+        for (int t = 0; t < C::KS; ++t)
+            s[kt] = T::mfma32(__builtin_bit_cast(vec8, ld16(krow + 16 * t)), qf[t], t == 0 ? zero : s[kt]);
+    }
+    {
+        bool move;
+        (void)sm_decide(H0{}, move);       // first half tile: sets the shift; O is zero, nothing to rescale
+        const float mc = m_run * c;
+        const f32x2 c2 = {c, c}, mc2 = {mc, mc};
+#pragma unroll
+        for (int un = 0; un < 8; ++un) sm_unit(H0{}, un, c2, mc2);
+    }
+
+    // All tiles but the last: every phase also runs the QK^T half of the NEXT tile.  The last tile is peeled (no
+    // branch on "is there a next tile" inside the loop: the two shapes of the body would otherwise make the
+    // compiler keep two copies of the O accumulators and copy between them).
+    for (int t = 0; t + 1 < ntiles; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        // Kbuf[nxt] held K(t-1) (last read by QK(t-1) in iteration t-2), Vbuf[cur] held V(t-2) (last read in iteration
+        // t-2): every wave has passed the barrier of iteration t-1, which follows iteration t-2 -> free to overwrite.
+        write_k(nxt);                 // K(t+1)
+        write_v(cur);                 // V(t)
+        if (t + 2 < ntiles) load_k(); // K(t+2)
+        load_v();                     // V(t+1)
+        __syncthreads();              // K(t+1), V(t) visible to all waves
+        __builtin_amdgcn_sched_barrier(0);
+        phase(H0{}, Yes{}, Yes{}, cur, nxt);   // O += V0(t) P0(t), S0(t+1)   ||  P1(t)
+        phase(H1{}, Yes{}, Yes{}, cur, nxt);   // O += V1(t) P1(t), S1(t+1)   ||  P0(t+1)
+    }
+    {
+        const int cur = (ntiles - 1) & 1;
+        write_v(cur);                 // V(n-1)
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        phase(H0{}, No{}, Yes{}, cur, cur);    // O += V0 P0   ||  P1
+        phase(H1{}, No{}, No{}, cur, cur);     // O += V1 P1
+    }
+
+    // ---- epilogue
+    const float l_tot = __shfl(o[C::MT - 1][ONES_R], l31);   // row DH of the V^T image is 1.0: sum of P from the MFMA
+    const float inv_l = 1.0f / l_tot;
+    if (q_ok) {
+        const int64_t op = b * p.o_bs + f * p.o_fs + (int64_t)q_row * (H * DH) + h * DH;
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d0 = mt * 32 + 8 * rg + 4 * hi;
+                if (d0 < DH) {
+                    f32x4 w;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) w[i] = o[mt][rg * 4 + i] * inv_l;
+                    store_out4<E, vec4>(p.out, op + d0, w, p.out_f32);
+                }
+            }
+    }
+}
+
+template <typename T, int MODE, int MINW>
+int launch_il40(AttnParams p, hipStream_t st) {
+    typedef AttnCfg<40, 64> C;
+    constexpr size_t lds = C::lds_bytes(1);
+    auto kern = ext_attn_il40_kernel<T, MODE, MINW>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    p.nQT = (p.S + 255) / 256;
+    const int per_branch = p.Kq * p.nQT * p.H;
+    const unsigned grid = (unsigned)(MODE == MODE_ALL ? (p.part == TF_ATTN_BANK_ONLY ? 2 : 3) * per_branch : per_branch);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
+    TF_LAUNCH_CHECK("tf_ext_attn_fwd");
+    return 0;
+}
+
 template <typename T, int DH, int MODE, int MINW>
 int launch_pp(AttnParams p, hipStream_t st) {
     typedef AttnCfg<DH, 64> C;
@@ -1213,12 +1543,20 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
         // -8..11 % on a sharded rank's level 0 against the 4-wave form); below that the 4-wave form (twice the
         // workgroups).  S < 256: always 4 waves.
         const bool big = p.S >= 256 && (int64_t)3 * p.Kq * ((p.S + 255) / 256) * p.H * p.nseg >= 768;
-        if (!p.fold)   // fp32 score scaling: the default
-            return compose([&] { return big ? launch_one<T, DH, 1, 8, MODE_ALL, 2, false>(p, st)
-                                            : launch_one<T, DH, 1, 4, MODE_ALL, 2, false>(p, st); },
+        if (!p.fold) {   // fp32 score scaling: the default
+#ifndef TF_TUNE_NO_IL40
+            const bool il = big && p.S % 64 == 0 && p.nseg == 1;   // half-tile interleaved form (ext_attn_il40_kernel)
+#else
+            const bool il = false;
+#endif
+            return compose([&] { return il    ? launch_il40<T, MODE_ALL, 4>(p, st)
+                                        : big ? launch_one<T, DH, 1, 8, MODE_ALL, 2, false>(p, st)
+                                              : launch_one<T, DH, 1, 4, MODE_ALL, 2, false>(p, st); },
                            [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 3, false>(p, st); },
-                           [&] { return big ? launch_one<T, DH, 1, 8, MODE_SOURCE, 2, false>(p, st)
-                                            : launch_one<T, DH, 1, 4, MODE_SOURCE, 2, false>(p, st); });
+                           [&] { return il    ? launch_il40<T, MODE_SOURCE, 4>(p, st)
+                                        : big ? launch_one<T, DH, 1, 8, MODE_SOURCE, 2, false>(p, st)
+                                              : launch_one<T, DH, 1, 4, MODE_SOURCE, 2, false>(p, st); });
+        }
         return compose([&] { return big ? launch_one<T, DH, 1, 8, MODE_ALL, 2>(p, st)
                                         : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st); },
                        [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 3>(p, st); },   // 151 VGPRs: 3 workgroups per CU
