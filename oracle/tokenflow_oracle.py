@@ -48,24 +48,25 @@ def ext_attn_core(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
     B, S, D = q.shape
     K = B // 3
     d = D // heads
+    dv = v.shape[-1] // heads            # the value width may differ from the q/k width (tests stack [V, |V|])
     q = q.reshape(3, K, S, heads, d)
     k = k.reshape(3, K, S, heads, d)
-    v = v.reshape(3, K, S, heads, d)
+    v = v.reshape(3, K, S, heads, dv)
     if inject:
         q = torch.stack([q[0], q[0], q[0]])
         k = torch.stack([k[0], k[0], k[0]])
-    out = torch.empty(3, K, S, heads, d, dtype=q.dtype)
+    out = torch.empty(3, K, S, heads, dv, dtype=q.dtype)
     # source branch: per-frame attention
     sim = torch.einsum("fqhc,fkhc->fhqk", q[0], k[0]) * scale
     out[0] = torch.einsum("fhqk,fkhc->fqhc", sim.softmax(dim=-1), v[0])
     # uncond / cond: bank of K*S keys shared by every frame of the branch
     for b in (1, 2):
         kb = k[b].reshape(K * S, heads, d)
-        vb = v[b].reshape(K * S, heads, d)
+        vb = v[b].reshape(K * S, heads, dv)
         for f in range(K):  # frame loop bounds the [h,S,K*S] score matrix
             sim = torch.einsum("qhc,khc->hqk", q[b, f], kb) * scale
             out[b, f] = torch.einsum("hqk,khc->qhc", sim.softmax(dim=-1), vb)
-    return out.reshape(3 * K, S, D)
+    return out.reshape(3 * K, S, heads * dv)
 
 
 def ext_attn_core_bmm(q, k, v, heads, scale, inject=False, frames=None):

@@ -44,8 +44,11 @@ def attn_ref(q, k, v, h, scale, inject, need_sigma=True):
     sigma = 2^-9/sqrt(3) * scale * max_k sqrt(sum_d (q_d k_d)^2)."""
     B, S, D = q.shape
     K, d = B // 3, D // h
-    if not need_sigma:
-        return (orc.ext_attn_core(q, k, v, h, scale, inject), orc.ext_attn_core(q, k, v.abs(), h, scale, inject), None)
+    if not need_sigma:   # one softmax for both: values stacked [V | |V|] per head
+        v4 = v.view(B, S, h, d)
+        both = orc.ext_attn_core(q, k, torch.cat([v4, v4.abs()], dim=-1).reshape(B, S, 2 * D), h, scale, inject)
+        both = both.view(B, S, h, 2 * d)
+        return both[..., :d].reshape(B, S, D), both[..., d:].reshape(B, S, D), None
     qs = (q.view(3, K, S, h, d) ** 2)
     ks = (k.view(3, K, S, h, d) ** 2)
     if inject:
