@@ -424,17 +424,18 @@ def test_fused_qkv_projection_matches_separate_projections(monkeypatch):
                           rtol=2.0 ** -6, atol=1e-3)
 
 
-def test_hipgraph_replay_of_hook_passes():
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_hipgraph_replay_of_hook_passes(dtype):
     """A pivotal pass and a propagation pass captured into HIP graphs (tokenflow_amd.graphs.GraphCache) replay to
-    the same bits as the eager passes, for new input contents."""
+    the same bits as the eager passes, for new input contents (bf16, and f16 -- the reference's own autocast dtype)."""
     from tokenflow_amd.graphs import GraphCache
-    holder, blk = _one_block_pipe(320, 8, "cuda", torch.bfloat16)
+    holder, blk = _one_block_pipe(320, 8, "cuda", dtype)
     K, n, S = 4, 2, 1024
     g = torch.Generator().manual_seed(3)
-    enc, enc_n = (torch.randn(3 * m, 7, 32, generator=g).cuda().bfloat16() for m in (K, n))
+    enc, enc_n = (torch.randn(3 * m, 7, 32, generator=g).cuda().to(dtype) for m in (K, n))
 
     def mk(m):
-        return torch.randn(3 * m, S, 320, generator=g).cuda().bfloat16()
+        return torch.randn(3 * m, S, 320, generator=g).cuda().to(dtype)
 
     def pivotal(x):
         tfu.register_pivotal(holder, True)
@@ -446,7 +447,7 @@ def test_hipgraph_replay_of_hook_passes():
         return blk(x, encoder_hidden_states=enc_n)
 
     cache = GraphCache()
-    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+    with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
         for rep in range(3):
             xp, xc = mk(K), mk(n)
             want_p = pivotal(xp).clone()
@@ -559,3 +560,46 @@ def test_ext_attn_interleaved_form_negative_first_tile():
     out = ops.ext_attn(q.bfloat16().cuda(), k.bfloat16().cuda(), v.bfloat16().cuda(), h, d ** -0.5, False)
     assert bool(torch.isfinite(out.float()).all())
     assert_attn_close(out, attn_ref(q, k, v, h, d ** -0.5, False, need_sigma=False), "interleaved, negative first tile")
+
+
+# ------------------------------------------------------------------------------------------- SDEdit installer, K > 12
+def test_sdedit_installer_many_keyframes():
+    """`register_extended_attention` (the SDEdit driver's installer, tokenflow_utils.py:216-294: never injects, not
+    even at t = 1000) + `set_tokenflow` on the stand-in UNet with K = 13 keyframes -- beyond the 12 up to which the
+    reference batches the frames of a pass (165-168) -- one block per level, pivotal pass and two chunks, against
+    pure fp32 `oracle.block_forward` (1e-3 of the output range, as in the config-1 test)."""
+    K, n = 13, 2
+    dev = torch.device("cuda")
+    torch.manual_seed(1)
+    pipe_cpu = fd.FakePipeline(dims=(320, 640, 1280), heads=8, cross_dim=32).eval()
+    pipe_gpu = copy.deepcopy(pipe_cpu).to(dev)
+    tfu.register_extended_attention(pipe_gpu)
+    tfu.set_tokenflow(pipe_gpu.unet)
+    tfu.register_time(pipe_gpu, 1000)
+    blocks_c = pipe_cpu.unet.transformer_blocks_in_order()
+    blocks_g = pipe_gpu.unet.transformer_blocks_in_order()
+    g = torch.Generator().manual_seed(3)
+    for idx, S in ((0, 256), (2, 64), (6, 16)):
+        (lvl, bc), (_, bg) = blocks_c[idx], blocks_g[idx]
+        D = (320, 640, 1280, 1280)[lvl]
+        base = torch.randn(S, D, generator=g)
+
+        def frames(m):
+            perm = torch.stack([torch.randperm(S, generator=g) for _ in range(m)])
+            return base[perm.reshape(-1)].view(m, S, D) + 0.1 * torch.randn(m, S, D, generator=g)
+        x = torch.cat([frames(K), torch.randn(2 * K, S, D, generator=g)])
+        enc, enc_n = torch.randn(3 * K, 7, 32, generator=g), torch.randn(3 * n, 7, 32, generator=g)
+        st = orc.BlockState()
+        with torch.no_grad():
+            tfu.register_pivotal(pipe_gpu, True)
+            got = bg(x.to(dev), encoder_hidden_states=enc.to(dev)).float().cpu()
+            ref = orc.block_forward(bc, st, x, pivotal=True, inject=False, encoder_hidden_states=enc)
+            assert float((got - ref).abs().max() / ref.abs().max()) <= 1e-3
+            tfu.register_pivotal(pipe_gpu, False)
+            for c in (0, 12):
+                xc = torch.cat([frames(n), torch.randn(2 * n, S, D, generator=g)])
+                tfu.register_batch_idx(pipe_gpu, c)
+                got = bg(xc.to(dev), encoder_hidden_states=enc_n.to(dev)).float().cpu()
+                ref = orc.block_forward(bc, st, xc, pivotal=False, batch_idx=c, encoder_hidden_states=enc_n)
+                assert got.dtype == ref.dtype
+                assert float((got - ref).abs().max() / ref.abs().max()) <= 1e-3, (idx, c)
