@@ -351,7 +351,7 @@ def test_ext_attn_strongly_negative_first_tile(d, dtype):
 
 # ------------------------------------------------------------------------------------------- multi-chunk propagation
 @pytest.mark.parametrize("K,n,S,D", [(8, 5, 4096, 320), (8, 5, 1024, 640), (4, 2, 64, 1280), (4, 2, 16, 1280),
-                                     (5, 3, 200, 72), (3, 8, 576, 1280)])
+                                     (5, 3, 200, 72), (3, 8, 576, 1280), (3, 3, 200, 320), (4, 1, 45, 320)])
 @pytest.mark.parametrize("first", [0, 1])
 @pytest.mark.parametrize("res_dtype", [torch.bfloat16, torch.float32])
 def test_propagate_chunks_equals_per_chunk_calls(K, n, S, D, first, res_dtype):
@@ -603,3 +603,33 @@ def test_sdedit_installer_many_keyframes():
                 ref = orc.block_forward(bc, st, xc, pivotal=False, batch_idx=c, encoder_hidden_states=enc_n)
                 assert got.dtype == ref.dtype
                 assert float((got - ref).abs().max() / ref.abs().max()) <= 1e-3, (idx, c)
+
+
+def test_hooks_multi_chunk_pass_on_gpu():
+    """`register_batch_idx(model, range(...))`: one pass over all chunks through the real kernels equals the
+    per-chunk passes bit for bit (bf16 block under autocast, as the reference runs)."""
+    holder, blk = _one_block_pipe(320, 8, "cuda", torch.bfloat16)
+    K, n, S = 4, 2, 256
+    g = torch.Generator().manual_seed(4)
+    enc = torch.randn(3 * K, 7, 32, generator=g).cuda().bfloat16()
+    enc_n = torch.randn(3 * n, 7, 32, generator=g).cuda().bfloat16()
+    x_piv = torch.randn(3 * K, S, 320, generator=g).cuda().bfloat16()
+    chunks = [torch.randn(3 * n, S, 320, generator=g).cuda().bfloat16() for _ in range(K)]
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        tfu.register_pivotal(holder, True)
+        blk(x_piv, encoder_hidden_states=enc)
+        tfu.register_pivotal(holder, False)
+        for first in (0, 1):
+            ref = []
+            for c in range(first, K):
+                tfu.register_batch_idx(holder, c)
+                ref.append(blk(chunks[c], encoder_hidden_states=enc_n).float().view(3, n, S, 320))
+            C = K - first
+            x_all = torch.stack([chunks[c].view(3, n, S, 320) for c in range(first, K)], dim=1).reshape(3 * C * n, S, 320)
+            enc_all = enc_n.view(3, 1, n, 7, 32).expand(3, C, n, 7, 32).reshape(3 * C * n, 7, 32)
+            tfu.register_batch_idx(holder, range(first, K))
+            got = blk(x_all, encoder_hidden_states=enc_all).float().view(3, C, n, S, 320)
+            want = torch.stack(ref, dim=1)
+            # the propagation itself is bit-identical; the layers behind it (fp32 chunk-0 rows arrive widened instead
+            # of bf16) may round differently in the last bf16 place
+            assert float((got - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max()), first
