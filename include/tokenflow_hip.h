@@ -235,6 +235,18 @@ int tf_layer_norm(const void* x, const void* gamma, const void* beta, void* out,
                   void* stream);
 
 /* ------------------------------------------------------------------------
+ * DDIM latent update  --  the step BEFORE the hot path (row f4): replaces preprocess.py:224-225 (ddim_inversion)
+ * and 259-260 (ddim_sample), six elementwise torch ops per UNet call in the loops that write / check the latents
+ * directory:
+ *     out = mu_b * ((x - sigma_a * eps) / mu_a) + sigma_b * eps          (n elements; out may alias x)
+ * inversion at step i:  a = timestep i-1 (mu_prev, sigma_prev), b = timestep i;  sampling: a = t, b = the next one.
+ * Same operation order and the same per-op rounding to `dtype` as the reference's sequence (fp32 scalars, no FMA,
+ * IEEE division): bit-identical to it in f32 / f16 / bf16.
+ * ------------------------------------------------------------------------ */
+int tf_ddim_step(const void* x, const void* eps, void* out, int64_t n, float mu_a, float sigma_a, float mu_b,
+                 float sigma_b, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
  * PnP feature injection  --  replaces tokenflow_utils.py:87-91:
  *   x viewed as [3, elems_per_branch]:  x[1] = x[0];  x[2] = x[0]   (in place)
  * elem_bytes = bytes per element; elems_per_branch*elem_bytes multiple of 16.

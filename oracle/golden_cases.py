@@ -117,3 +117,43 @@ def adazero_inputs():
     return dict(pivotal=x_piv, chunks=chunks, enc=torch.randn(3 * K, 7, cfg["cross_dim"], generator=g),
                 enc_n=torch.randn(3 * n, 7, cfg["cross_dim"], generator=g),
                 timestep=torch.tensor([cfg["timestep"]]))
+
+
+INVERSION_CFG = dict(F=6, H=8, W=8, steps=10, batch_size=4, seed=31)
+
+
+class _Sample:
+    def __init__(self, sample):
+        self.sample = sample
+
+
+class InversionModel:
+    """The `self` that `Preprocess.ddim_inversion` / `ddim_sample` (preprocess.py:198-261) consume: a scheduler with
+    `timesteps`, `alphas_cumprod`, `final_alpha_cumprod` (a 1000-step scaled-linear beta schedule, as SD's DDIM
+    scheduler), a deterministic stand-in UNet and `sd_version`."""
+
+    def __init__(self):
+        cfg = INVERSION_CFG
+        betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+        self.scheduler = type("Sched", (), {})()
+        self.scheduler.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.scheduler.final_alpha_cumprod = torch.tensor(1.0)
+        step = 1000 // cfg["steps"]
+        self.scheduler.timesteps = (torch.arange(0, cfg["steps"]) * step).flip(0) + 1      # 901, 801, ..., 1
+        self.sd_version = "1.5"
+        g = torch.Generator().manual_seed(cfg["seed"])
+        self.w = 0.3 * torch.randn(4, 4, generator=g)
+
+    def unet(self, model_input, t, encoder_hidden_states=None):
+        # a smooth, timestep- and prompt-dependent function of the latents (stands for the noise prediction)
+        mixed = torch.einsum("oc,fchw->fohw", self.w.to(model_input.dtype), model_input)
+        eps = torch.tanh(mixed + 0.1 * torch.roll(model_input, 1, dims=-1)) * (0.5 + float(t) / 2000.0)
+        return _Sample(eps + encoder_hidden_states.mean().to(model_input.dtype) * 0.01)
+
+
+def inversion_inputs(dtype=torch.float32):
+    cfg = INVERSION_CFG
+    g = torch.Generator().manual_seed(cfg["seed"] + 1)
+    latents = torch.randn(cfg["F"], 4, cfg["H"], cfg["W"], generator=g).to(dtype)
+    cond = torch.randn(1, 7, 16, generator=g).to(dtype)
+    return latents, cond

@@ -23,6 +23,9 @@ Fixtures
                  per-block outputs of the pivotal pass and of chunks 0..2, and the
                  patched resnet forward.  Module weights come from a seed; a
                  checksum guards against RNG drift.
+  inversion.pt   Preprocess.ddim_inversion / ddim_sample (preprocess.py:198-261), cut out of the reference's
+                 syntax tree and executed unchanged on a stand-in model: the latents files written
+                 (names + contents), the inverted and the reconstructed latents.  fp32.
   adazero.pt     TokenFlowBlock.forward on an AdaLayerNormZero block (use_ada_layer_norm_zero:
                  gate_msa on the cached / selected attention outputs, 362-366; scale/shift/gate
                  on the feed-forward, 417-424): pivotal pass and chunks 0..K-1.
@@ -200,6 +203,42 @@ def gen_adazero(tfu):
     return out
 
 
+def load_reference_inversion():
+    """`Preprocess.ddim_inversion` and `Preprocess.ddim_sample` of the VERBATIM reference as plain functions.
+    preprocess.py imports diffusers / transformers at module level and cannot be imported here, so the two method
+    definitions are cut out of its syntax tree and compiled unchanged (decorators included) in a namespace that
+    holds what their bodies use: torch, os and a pass-through tqdm."""
+    import ast
+    src = open(os.path.join(ref_loader.REF_ROOT, "preprocess.py")).read()
+    tree = ast.parse(src)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "Preprocess")
+    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("ddim_inversion", "ddim_sample")]
+    assert len(fns) == 2
+    ns = {"torch": torch, "os": os, "tqdm": lambda it: it}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "preprocess.py", "exec"), ns)
+    return ns["ddim_inversion"], ns["ddim_sample"]
+
+
+def gen_inversion():
+    """The verbatim inversion / reconstruction loops (preprocess.py:198-261) on the stand-in model, fp32 latents:
+    the files they write and the tensors they return."""
+    import tempfile
+    ref_inv, ref_sample = load_reference_inversion()
+    model = gc.InversionModel()
+    latents, cond = gc.inversion_inputs()
+    out = dict(input_checksum=gc.checksum(latents, cond), files={})
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "latents"))
+        save_ts = model.scheduler.timesteps[::2]
+        inv = ref_inv(model, cond, latents.clone(), d, gc.INVERSION_CFG["batch_size"], save_latents=True,
+                      timesteps_to_save=save_ts)
+        for f in sorted(os.listdir(os.path.join(d, "latents"))):
+            out["files"][f] = digest(torch.load(os.path.join(d, "latents", f)), 3)
+        out["inverted"] = digest(inv, 1)
+        out["reconstructed"] = digest(ref_sample(model, inv.clone(), cond, gc.INVERSION_CFG["batch_size"]), 1)
+    return out
+
+
 def main():
     tfu, util = ref_loader.load()
     os.makedirs(GOLDEN, exist_ok=True)
@@ -207,6 +246,7 @@ def main():
     torch.save(gen_propagate(tfu, util), os.path.join(GOLDEN, "propagate.pt"))
     torch.save(gen_blocks(tfu), os.path.join(GOLDEN, "blocks.pt"))
     torch.save(gen_adazero(tfu), os.path.join(GOLDEN, "adazero.pt"))
+    torch.save(gen_inversion(), os.path.join(GOLDEN, "inversion.pt"))
     for f in sorted(os.listdir(GOLDEN)):
         print(f, os.path.getsize(os.path.join(GOLDEN, f)) // 1024, "KiB")
 

@@ -246,6 +246,25 @@ def conv_inject_(hidden_states: torch.Tensor) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------
+# (D) DDIM latent update  --  preprocess.py:224-225 (inversion), 259-260 (sampling)
+# ---------------------------------------------------------------------------
+
+def ddim_step(x: torch.Tensor, eps: torch.Tensor, mu_a: float, sigma_a: float, mu_b: float,
+              sigma_b: float) -> torch.Tensor:
+    """`pred_x0 = (x - sigma_a*eps) / mu_a;  x' = mu_b*pred_x0 + sigma_b*eps` with the reference's operation
+    order and per-op rounding: every torch op on a 16-bit tensor is evaluated in fp32 and rounded to the tensor
+    dtype, the coefficients are fp32 scalars (on the reference's CUDA path `scheduler.alphas_cumprod` is a host
+    tensor, i.e. a scalar operand kept in fp32 opmath -- a CPU run of the same lines would round the scalars to the
+    tensor dtype first, which is why the fp16 golden of this step is generated in fp32 only)."""
+    dt = x.dtype
+    r = (lambda t: t) if dt == torch.float32 else (lambda t: t.to(dt).float())
+    xf, ef = x.float(), eps.float()
+    f32 = lambda v: torch.tensor(v, dtype=torch.float32)
+    pred_x0 = r(r(xf - r(f32(sigma_a) * ef)) / f32(mu_a))
+    return r(r(f32(mu_b) * pred_x0) + r(f32(sigma_b) * ef)).to(dt)
+
+
+# ---------------------------------------------------------------------------
 # whole-block restatement  --  tokenflow_utils.py:300-427
 # ---------------------------------------------------------------------------
 

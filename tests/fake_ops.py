@@ -145,6 +145,10 @@ class FakeOps:
             outs.append(o.to(out_dtype).view(3, n, S, D))
         return torch.stack(outs, dim=1).reshape(3 * n_chunks * n, S, D)
 
+    def ddim_step(self, x, eps, mu_a, sigma_a, mu_b, sigma_b, out=None):
+        res = orc.ddim_step(x, eps, mu_a, sigma_a, mu_b, sigma_b)
+        return res if out is None else out.copy_(res)
+
     def inject_copy_(self, x):
         self.calls.append(("inject_copy_", tuple(x.shape)))
         return orc.conv_inject_(x)

@@ -633,3 +633,47 @@ def test_hooks_multi_chunk_pass_on_gpu():
             # the propagation itself is bit-identical; the layers behind it (fp32 chunk-0 rows arrive widened instead
             # of bf16) may round differently in the last bf16 place
             assert float((got - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max()), first
+
+
+# ------------------------------------------------------------------------------------------- row f4: DDIM update
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_ddim_step_bit_exact(dtype):
+    """tf_ddim_step against the oracle's restatement of preprocess.py:224-225 (per-op rounding to the tensor dtype,
+    fp32 scalars, no FMA, IEEE division): bit-exact, out of place and in place, at the reference's latents size
+    (40 x 4 x 64 x 64) and at an odd element count."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    for shape in ((40, 4, 64, 64), (3, 4, 9, 5)):
+        x, eps = (torch.randn(*shape, generator=g).to(dtype) for _ in range(2))
+        co = (0.9734, 0.2291, 0.9581, 0.2864)
+        ref = orc.ddim_step(x, eps, *co)
+        dx = x.cuda()
+        out = ops.ddim_step(dx, eps.cuda(), *co)
+        assert out.dtype == dtype and torch.equal(out.cpu(), ref)
+        assert torch.equal(dx.cpu(), x)
+        ops.ddim_step(dx, eps.cuda(), *co, out=dx)
+        assert torch.equal(dx.cpu(), ref)
+
+
+def test_ddim_inversion_on_gpu_against_reference_golden(tmp_path):
+    """The inversion + reconstruction loops of `tokenflow_amd.inversion` on the GPU (HIP update kernel, stand-in
+    UNet evaluated by torch on the GPU) against the verbatim reference's CPU run: 2e-5 (the stand-in's tanh differs
+    between the two devices in the last fp32 bits; the update itself is bit-exact, test above)."""
+    import os
+    from oracle import golden_cases as gc
+    from oracle.golden_util import check
+    from tests.conftest import load_golden
+    from tokenflow_amd import inversion
+    g = load_golden("inversion.pt")
+    model = gc.InversionModel()
+    model.w = model.w.cuda()
+    latents, cond = gc.inversion_inputs()
+    os.makedirs(tmp_path / "latents")
+    inv = inversion.ddim_inversion(model, cond.cuda(), latents.cuda(), str(tmp_path), gc.INVERSION_CFG["batch_size"],
+                                   save_latents=True, timesteps_to_save=model.scheduler.timesteps[::2])
+    assert sorted(os.listdir(tmp_path / "latents")) == sorted(g["files"])
+    for name, dg in g["files"].items():
+        check(torch.load(tmp_path / "latents" / name).cpu(), dg, 2e-5, name)
+    check(inv.cpu(), g["inverted"], 2e-5, "inverted")
+    rec = inversion.ddim_sample(model, inv.clone(), cond.cuda(), gc.INVERSION_CFG["batch_size"])
+    check(rec.cpu(), g["reconstructed"], 2e-4, "reconstructed")

@@ -313,3 +313,32 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name)
     assert lib.tf_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define TF_ABI_VERSION (\d+)", hdr).group(1))
+
+
+def test_ddim_inversion_matches_reference_golden(tmp_path, monkeypatch):
+    """Row f4: `tokenflow_amd.inversion.ddim_inversion` / `ddim_sample` (latent update through the oracle-backed
+    `ddim_step`) against what the VERBATIM `Preprocess.ddim_inversion` / `ddim_sample` (preprocess.py:198-261,
+    executed unchanged by oracle/make_golden.py) wrote and returned: same file names, same contents bit for bit in
+    fp32 (same operation order, no fused multiply-add), same in-place update of the caller's tensor."""
+    import os
+    from tests.conftest import load_golden
+    from tokenflow_amd import inversion
+    monkeypatch.setattr(inversion, "ops", FakeOps())
+    g = load_golden("inversion.pt")
+    model = gc.InversionModel()
+    latents, cond = gc.inversion_inputs()
+    assert gc.checksum(latents, cond) == g["input_checksum"], "RNG drift"
+    os.makedirs(tmp_path / "latents")
+    work = latents.clone()
+    inv = inversion.ddim_inversion(model, cond, work, str(tmp_path), gc.INVERSION_CFG["batch_size"], save_latents=True,
+                                   timesteps_to_save=model.scheduler.timesteps[::2])
+    assert inv is work                                                   # updated in place, as the reference
+    assert sorted(os.listdir(tmp_path / "latents")) == sorted(g["files"])
+    for name, dg in g["files"].items():
+        check(torch.load(tmp_path / "latents" / name), dg, 0.0, name)
+        assert tfu.load_source_latents_t(int(name.split("_")[-1][:-3]), str(tmp_path / "latents")).shape == dg["shape"]
+    check(inv, g["inverted"], 0.0, "inverted")
+    check(inversion.ddim_sample(model, inv.clone(), cond, gc.INVERSION_CFG["batch_size"]), g["reconstructed"], 0.0,
+          "reconstructed")
+    assert inversion.latents_save_path("latents", "2.1", "data/wolf.mp4", 500, 40) == \
+        os.path.join("latents", "sd_2.1", "wolf", "steps_500", "nframes_40")       # preprocess.py:305-309

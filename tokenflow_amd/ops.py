@@ -354,3 +354,19 @@ def inject_copy_(x: torch.Tensor) -> torch.Tensor:
     per_branch = x.numel() // 3
     _launch(dev, "tf_inject_copy", lib.tf_inject_copy, x.data_ptr(), per_branch, x.element_size())
     return x
+
+
+def ddim_step(x: torch.Tensor, eps: torch.Tensor, mu_a: float, sigma_a: float, mu_b: float, sigma_b: float,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = mu_b * ((x - sigma_a*eps) / mu_a) + sigma_b*eps  (preprocess.py:224-225 / 259-260), one launch, the
+    reference's per-op rounding.  x, eps: same shape and dtype (f16 / bf16 / f32), contiguous; out may be x."""
+    dev = _need_gpu(x, eps, out)
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty_like(x)
+    if (eps.shape != x.shape or eps.dtype != x.dtype or out.shape != x.shape or out.dtype != x.dtype
+            or x.dtype not in _DT or not (x.is_contiguous() and eps.is_contiguous() and out.is_contiguous())):
+        raise ValueError("ddim_step: x, eps, out must be contiguous tensors of one shape and dtype (f16/bf16/f32)")
+    _launch(dev, "tf_ddim_step", lib.tf_ddim_step, x.data_ptr(), eps.data_ptr(), out.data_ptr(), x.numel(),
+            float(mu_a), float(sigma_a), float(mu_b), float(sigma_b), _DT[x.dtype])
+    return out
