@@ -460,7 +460,8 @@ def test_hipgraph_replay_of_hook_passes(dtype):
 
 
 # ------------------------------------------------------------------------------------------- collective-shaped layouts
-@pytest.mark.parametrize("K,S,h,d", [(4, 320, 2, 40), (3, 136, 2, 64), (2, 264, 1, 80), (2, 72, 1, 160), (5, 1024, 1, 40)])
+@pytest.mark.parametrize("K,S,h,d", [(4, 320, 2, 40), (3, 136, 2, 64), (2, 264, 1, 80), (2, 72, 1, 160), (5, 1024, 1, 40),
+                                     (4, 4096, 8, 40)])       # the last one: the interleaved Dh = 40 kernel
 @pytest.mark.parametrize("inject", [False, True])
 def test_ext_attn_strided_views_equal_dense(K, S, h, d, inject, monkeypatch):
     """tf_ext_attn_fwd_strided on the buffers of the head re-sharding -- q / k / v read from a [frame][slab][S][D]
@@ -677,3 +678,17 @@ def test_ddim_inversion_on_gpu_against_reference_golden(tmp_path):
     check(inv.cpu(), g["inverted"], 2e-5, "inverted")
     rec = inversion.ddim_sample(model, inv.clone(), cond.cuda(), gc.INVERSION_CFG["batch_size"])
     check(rec.cpu(), g["reconstructed"], 2e-4, "reconstructed")
+
+
+def test_ext_attn_interleaved_form_query_frame_subset(monkeypatch):
+    """The interleaved kernel with the queries of a frame subset against the full bank (what a rank of the
+    bank-all-gather exchange computes: Kq = 2 of K = 4 frames, q_frame0 = 2): equal to the matching slices of the
+    full call, bit for bit."""
+    ops = _ops()
+    monkeypatch.setattr(ops, "NO_SPLIT", True)
+    K, S, h, d = 4, 4096, 8, 40
+    g = torch.Generator(device="cuda").manual_seed(12)
+    q, k, v = (torch.randn(3 * K, S, h * d, generator=g, device="cuda").bfloat16() for _ in range(3))
+    full = ops.ext_attn(q, k, v, h, d ** -0.5, False).view(3, K, S, h * d)
+    part = ops.ext_attn(q.view(3, K, S, h * d)[:, 2:4].reshape(6, S, h * d), k, v, h, d ** -0.5, False, q_frame0=2)
+    assert torch.equal(part.view(3, 2, S, h * d), full[:, 2:4])
