@@ -234,6 +234,16 @@ int tf_layer_norm(const void* x, const void* gamma, const void* beta, void* out,
                   int64_t rows, int D, float eps, int in_dtype, int w_dtype, int out_dtype,
                   void* stream);
 
+/* Residual add + LayerNorm  --  `hidden_states = attn_output + hidden_states` followed by the block's next norm
+ * (tokenflow_utils.py:396-403 and 409-414), one pass instead of an add kernel plus a norm:
+ *   sum_out[r] = round_to(sum_dtype, a[r] + b[r])        (what torch's `a + b` stores: fp32 add, promoted dtype)
+ *   out[r]     = LayerNorm(sum_out[r])                   (as tf_layer_norm, on the ROUNDED sum)
+ * a, b, sum_out: [rows, D] of a_dtype / b_dtype / sum_dtype.  Results are bit-identical to the add followed by
+ * tf_layer_norm. */
+int tf_add_layer_norm(const void* a, const void* b, void* sum_out, const void* gamma, const void* beta, void* out,
+                      int64_t rows, int D, float eps, int a_dtype, int b_dtype, int sum_dtype, int w_dtype,
+                      int out_dtype, void* stream);
+
 /* ------------------------------------------------------------------------
  * DDIM latent update  --  the step BEFORE the hot path (row f4): replaces preprocess.py:224-225 (ddim_inversion)
  * and 259-260 (ddim_sample), six elementwise torch ops per UNet call in the loops that write / check the latents

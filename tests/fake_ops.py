@@ -124,6 +124,10 @@ class FakeOps:
                                            None if bias is None else bias.float(), eps).to(out_dtype)
         return y, (1.0 / y.float().norm(dim=-1) if want_inv_norm else None)
 
+    def add_layer_norm(self, a, b, weight, bias, eps, out_dtype):
+        total = a + b
+        return total, self.layer_norm(total, weight, bias, eps, out_dtype)[0]
+
     def propagate(self, tgt, piv, inv_norm, kf_ids, kf_out, w, n, residual, out_dtype):
         return self.gather_blend(kf_out, self.nn_search(tgt, piv, inv_norm, kf_ids), w, kf_ids, n, residual, out_dtype)
 

@@ -210,15 +210,17 @@ def test_hooks_16bit_block_uses_fused_norm_and_matches_module_norm():
             b = blk(chunk, encoder_hidden_states=enc_n)
         return a.float(), b.float(), inv
 
-    calls = []
-    real = hooks.ops.layer_norm
-    spy = lambda *a, **k: (calls.append(a[0].shape), real(*a, **k))[1]
-    hooks.ops.layer_norm = spy
+    calls, add_calls = [], []
+    real, real_add = hooks.ops.layer_norm, hooks.ops.add_layer_norm
+    hooks.ops.layer_norm = lambda *a, **k: (calls.append(a[0].shape), real(*a, **k))[1]
+    hooks.ops.add_layer_norm = lambda *a, **k: (add_calls.append(a[0].shape), real_add(*a, **k))[1]
     try:
         fused = run()
     finally:
-        hooks.ops.layer_norm = real
-    assert len(calls) == 6                         # norm1, norm2, norm3 in both passes
+        hooks.ops.layer_norm, hooks.ops.add_layer_norm = real, real_add
+    # norm1, norm2, norm3 in both passes: a norm that follows a residual add takes the add with it
+    # (pivotal: norm2, norm3; propagation: norm3 -- its self-attention residual is added by the gather kernel)
+    assert len(calls) == 3 and len(add_calls) == 3
     keep = hooks._fused_norm_dtype
     hooks._fused_norm_dtype = lambda mod, x: None
     try:

@@ -484,3 +484,22 @@ def test_layer_norm_argument_errors():
         ops.layer_norm(x, None, None, 1e-5, torch.bfloat16)          # D > 2048
     with pytest.raises(TokenflowHipError):
         ops.layer_norm(x[:, :12], None, None, 1e-5, torch.bfloat16)  # D % 8
+
+
+@pytest.mark.parametrize("rows,D", [(4096, 320), (515, 640), (37, 1280), (5, 72)])
+@pytest.mark.parametrize("a_dt,b_dt,out_dt", [
+    (torch.bfloat16, torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32, torch.bfloat16),
+    (torch.float32, torch.bfloat16, torch.bfloat16), (torch.float16, torch.float16, torch.float16),
+    (torch.float32, torch.float32, torch.float32)])
+def test_add_layer_norm_equals_add_then_norm(rows, D, a_dt, b_dt, out_dt):
+    """tf_add_layer_norm == torch's `a + b` (promoted dtype, one rounding) followed by tf_layer_norm, bit for bit."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows + D)
+    a = (torch.randn(rows, D, generator=g) * 2).to(a_dt).cuda()
+    b = (torch.randn(rows, D, generator=g) + 0.3).to(b_dt).cuda()
+    w = (1 + 0.2 * torch.randn(D, generator=g)).cuda()
+    bias = (0.1 * torch.randn(D, generator=g)).cuda()
+    total, out = ops.add_layer_norm(a, b, w, bias, 1e-5, out_dt)
+    want_total = a + b
+    assert total.dtype == want_total.dtype and torch.equal(total, want_total)
+    assert torch.equal(out, ops.layer_norm(want_total, w, bias, 1e-5, out_dt)[0])

@@ -68,6 +68,22 @@ __device__ __forceinline__ void ln_load_w(const void* w, int w_dtype, int col, f
     }
 }
 
+// residual-add form (tf_add_layer_norm): rounds the 8 sums to `dtype` (what torch's `a + b` stores), writes them and
+// leaves the ROUNDED values in f -- the LayerNorm then sees exactly the tensor the reference normalises
+__device__ __forceinline__ void ln_store_sum(void* p, int dtype, int64_t off, float (&f)[8]) {
+    if (dtype == TF_F32) {
+        (void)ln_store8(reinterpret_cast<float*>(p) + off, f);
+    } else if (dtype == TF_BF16) {
+        (void)ln_store8(reinterpret_cast<__bf16*>(p) + off, f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (float)(__bf16)f[i];
+    } else {
+        (void)ln_store8(reinterpret_cast<_Float16*>(p) + off, f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (float)(_Float16)f[i];
+    }
+}
+
 // sum over the LPR lanes that share a row (LPR = 16, 32 or 64 consecutive lanes)
 template <int LPR>
 __device__ __forceinline__ float row_sum(float x) {
@@ -81,11 +97,16 @@ constexpr int LN_MAXP = 4;   // 16-B pieces per lane
 // LPR lanes per row, 64/LPR rows per wave: a row of D = 320 is 40 pieces -- with a whole wave per row a third of
 // the lanes idle and every row pays three full-wave reductions; 16 lanes per row keep all lanes busy on 4 rows.
 // D <= LPR * 8 * LN_MAXP.
-template <typename TIn, typename TOut, int LPR>
+// ADD: the input row is `x + res` (res of runtime dtype res_dtype), rounded to sum_dtype and written to sum_out
+// first -- `hidden_states = attn_output + hidden_states` followed by the next norm of the block
+// (tokenflow_utils.py:396-403, 409-414) in one pass.
+template <typename TIn, typename TOut, int LPR, bool ADD = false>
 __global__ __launch_bounds__(256) void layer_norm_kernel(const TIn* __restrict__ x, const void* __restrict__ gamma,
                                                          const void* __restrict__ beta, TOut* __restrict__ out,
                                                          float* __restrict__ inv_norm, int64_t rows, int D, float eps,
-                                                         int w_dtype) {
+                                                         int w_dtype, const void* __restrict__ res = nullptr,
+                                                         int res_dtype = 0, void* __restrict__ sum_out = nullptr,
+                                                         int sum_dtype = 0) {
     constexpr int RPW = 64 / LPR;   // rows per wave
     const int lane = threadIdx.x & 63;
     const int lr = lane % LPR;      // lane within its row
@@ -101,6 +122,15 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const TIn* __restrict__
             const int p = lr + LPR * j;
             if (p < pieces) {
                 ln_load8(xr + p * 8, v[j]);
+                if constexpr (ADD) {
+                    float rr[8];
+                    if (res_dtype == TF_F32) ln_load8(reinterpret_cast<const float*>(res) + r * D + p * 8, rr);
+                    else if (res_dtype == TF_BF16) ln_load8(reinterpret_cast<const __bf16*>(res) + r * D + p * 8, rr);
+                    else ln_load8(reinterpret_cast<const _Float16*>(res) + r * D + p * 8, rr);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[j][i] = __fadd_rn(v[j][i], rr[i]);
+                    ln_store_sum(sum_out, sum_dtype, r * D + p * 8, v[j]);
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) s += v[j][i];
             }
@@ -138,32 +168,44 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const TIn* __restrict__
     }
 }
 
+struct LnAdd {   // residual-add form: nullptr res = plain LayerNorm
+    const void* res;
+    int res_dtype;
+    void* sum_out;
+    int sum_dtype;
+};
+
 template <typename TIn, typename TOut, int LPR>
 void launch_ln_lpr(const void* x, const void* gamma, const void* beta, void* out, float* inv_norm, int64_t rows,
-                   int D, float eps, int w_dtype, hipStream_t st) {
+                   int D, float eps, int w_dtype, hipStream_t st, const LnAdd& ad) {
     constexpr int rows_per_wg = 4 * (64 / LPR);
     int64_t blocks = (rows + rows_per_wg - 1) / rows_per_wg;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL((layer_norm_kernel<TIn, TOut, LPR>), dim3((unsigned)blocks), dim3(256), 0, st,
-                       reinterpret_cast<const TIn*>(x), gamma, beta, reinterpret_cast<TOut*>(out), inv_norm, rows, D,
-                       eps, w_dtype);
+    if (ad.res)
+        hipLaunchKernelGGL((layer_norm_kernel<TIn, TOut, LPR, true>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           reinterpret_cast<const TIn*>(x), gamma, beta, reinterpret_cast<TOut*>(out), inv_norm, rows, D,
+                           eps, w_dtype, ad.res, ad.res_dtype, ad.sum_out, ad.sum_dtype);
+    else
+        hipLaunchKernelGGL((layer_norm_kernel<TIn, TOut, LPR, false>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           reinterpret_cast<const TIn*>(x), gamma, beta, reinterpret_cast<TOut*>(out), inv_norm, rows, D,
+                           eps, w_dtype, nullptr, 0, nullptr, 0);
 }
 
 template <typename TIn, typename TOut>
 void launch_ln(const void* x, const void* gamma, const void* beta, void* out, float* inv_norm, int64_t rows, int D,
-               float eps, int w_dtype, hipStream_t st) {
-    if (D <= 16 * 8 * LN_MAXP) launch_ln_lpr<TIn, TOut, 16>(x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st);
-    else if (D <= 32 * 8 * LN_MAXP) launch_ln_lpr<TIn, TOut, 32>(x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st);
-    else launch_ln_lpr<TIn, TOut, 64>(x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st);
+               float eps, int w_dtype, hipStream_t st, const LnAdd& ad) {
+    if (D <= 16 * 8 * LN_MAXP) launch_ln_lpr<TIn, TOut, 16>(x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st, ad);
+    else if (D <= 32 * 8 * LN_MAXP) launch_ln_lpr<TIn, TOut, 32>(x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st, ad);
+    else launch_ln_lpr<TIn, TOut, 64>(x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st, ad);
 }
 
 template <typename TIn>
 void dispatch_ln_out(int out_dtype, const void* x, const void* gamma, const void* beta, void* out, float* inv_norm,
-                     int64_t rows, int D, float eps, int w_dtype, hipStream_t st) {
+                     int64_t rows, int D, float eps, int w_dtype, hipStream_t st, const LnAdd& ad = LnAdd{}) {
     switch (out_dtype) {
-        case TF_BF16: launch_ln<TIn, __bf16>(x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st); break;
-        case TF_F16: launch_ln<TIn, _Float16>(x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st); break;
-        default: launch_ln<TIn, float>(x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st); break;
+        case TF_BF16: launch_ln<TIn, __bf16>(x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st, ad); break;
+        case TF_F16: launch_ln<TIn, _Float16>(x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st, ad); break;
+        default: launch_ln<TIn, float>(x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st, ad); break;
     }
 }
 
@@ -187,5 +229,29 @@ extern "C" int tf_layer_norm(const void* x, const void* gamma, const void* beta,
         default: dispatch_ln_out<float>(out_dtype, x, gamma, beta, out, inv_norm, rows, D, eps, w_dtype, st); break;
     }
     TF_LAUNCH_CHECK("tf_layer_norm");
+    return 0;
+}
+
+extern "C" int tf_add_layer_norm(const void* a, const void* b, void* sum_out, const void* gamma, const void* beta,
+                                 void* out, int64_t rows, int D, float eps, int a_dtype, int b_dtype, int sum_dtype,
+                                 int w_dtype, int out_dtype, void* stream) {
+    TF_ARG(a && b && sum_out && out, TF_ERR_NULL, "tf_add_layer_norm: null pointer");
+    auto okdt = [](int d) { return d == TF_BF16 || d == TF_F16 || d == TF_F32; };
+    TF_ARG(okdt(a_dtype) && okdt(b_dtype) && okdt(sum_dtype) && okdt(out_dtype) && ((!gamma && !beta) || okdt(w_dtype)),
+           TF_ERR_DTYPE, "tf_add_layer_norm: dtypes a=%d b=%d sum=%d w=%d out=%d", a_dtype, b_dtype, sum_dtype, w_dtype,
+           out_dtype);
+    TF_ARG(rows > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * LN_MAXP, TF_ERR_SHAPE,
+           "tf_add_layer_norm: rows=%lld D=%d (D %% 8 == 0, D <= %d)", (long long)rows, D, 64 * 8 * LN_MAXP);
+    TF_ARG(tf_aligned16(a) && tf_aligned16(b) && tf_aligned16(sum_out) && tf_aligned16(out) && tf_aligned16(gamma) &&
+               tf_aligned16(beta),
+           TF_ERR_ALIGN, "tf_add_layer_norm: tensors not 16-byte aligned");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const LnAdd ad{b, b_dtype, sum_out, sum_dtype};
+    switch (a_dtype) {
+        case TF_BF16: dispatch_ln_out<__bf16>(out_dtype, a, gamma, beta, out, nullptr, rows, D, eps, w_dtype, st, ad); break;
+        case TF_F16: dispatch_ln_out<_Float16>(out_dtype, a, gamma, beta, out, nullptr, rows, D, eps, w_dtype, st, ad); break;
+        default: dispatch_ln_out<float>(out_dtype, a, gamma, beta, out, nullptr, rows, D, eps, w_dtype, st, ad); break;
+    }
+    TF_LAUNCH_CHECK("tf_add_layer_norm");
     return 0;
 }

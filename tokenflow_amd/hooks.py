@@ -333,19 +333,21 @@ def _blend_weights(n: int, device) -> torch.Tensor:
     return w
 
 
-def _fused_norm_dtype(mod: torch.nn.Module, x: torch.Tensor):
+def _fused_norm_dtype(mod: torch.nn.Module, x: torch.Tensor, in_dtype=None):
     """The 16-bit dtype in which a plain LayerNorm of the block can be produced directly by
     `ops.layer_norm` (one pass instead of torch's autocast sequence cast-up / fp32 norm / cast-down in front
-    of the next Linear), or None: keep the module call (fp32 models, AdaLayerNorm, CPU tensors)."""
+    of the next Linear), or None: keep the module call (fp32 models, AdaLayerNorm, CPU tensors).
+    in_dtype: dtype of the norm's input when it is not x's (the residual-add form normalises `a + x`)."""
     D = x.shape[-1]
+    in_dtype = x.dtype if in_dtype is None else in_dtype
     if (type(mod) is not torch.nn.LayerNorm or not x.is_cuda or tuple(mod.normalized_shape) != (D,)
-            or D % 8 or D > 2048 or x.dtype not in (torch.float32, torch.bfloat16, torch.float16)):
+            or D % 8 or D > 2048 or in_dtype not in (torch.float32, torch.bfloat16, torch.float16)):
         return None
     if torch.is_autocast_enabled("cuda"):
         dt = torch.get_autocast_dtype("cuda")
         return dt if dt in (torch.bfloat16, torch.float16) else None
-    if x.dtype != torch.float32 and (mod.weight is None or mod.weight.dtype == x.dtype):
-        return x.dtype
+    if in_dtype != torch.float32 and (mod.weight is None or mod.weight.dtype == in_dtype):
+        return in_dtype
     return None
 
 
@@ -364,6 +366,18 @@ def _block_norm(mod: torch.nn.Module, x: torch.Tensor, want_inv_norm: bool = Fal
     if dt is None:
         return mod(x), None
     return ops.layer_norm(x, mod.weight, mod.bias, mod.eps, dt, want_inv_norm)
+
+
+def _add_norm(mod: torch.nn.Module, a: torch.Tensor, h: torch.Tensor, which: str):
+    """(a + h, LayerNorm(a + h)): the residual add of the block and the norm that follows it
+    (`hidden_states = attn_output + hidden_states` then norm2 / norm3, tokenflow_utils.py:396-403, 409-414) in one
+    pass through `ops.add_layer_norm` when the norm is fusable, else the two torch ops.  Bit-identical either way."""
+    if a.shape == h.shape and a.is_cuda and h.is_cuda and (FUSE_NORMS == "all" or FUSE_NORMS == which):
+        dt = _fused_norm_dtype(mod, h, torch.promote_types(a.dtype, h.dtype))
+        if dt is not None:
+            return ops.add_layer_norm(a, h, mod.weight, mod.bias, mod.eps, dt)
+    total = a + h
+    return total, _block_norm(mod, total, which=which)[0]
 
 
 def _chunk_run(batch_idx):
@@ -393,6 +407,7 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
 
             norm_inv = None
             gate_msa = None
+            pending = None          # a residual branch output not yet added to hidden_states (see _add_norm)
             if self.use_ada_layer_norm:
                 norm_hidden_states = self.norm1(hidden_states, timestep)
             elif self.use_ada_layer_norm_zero:
@@ -419,8 +434,8 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
                     self.attn_output = gate_msa.unsqueeze(1) * self.attn_output
                 attn_output = self.attn_output
                 hidden_states = hidden_states.reshape(batch_size, sequence_length, dim)
-                hidden_states = attn_output + hidden_states
-            else:
+                pending = attn_output              # `hidden_states = attn_output + hidden_states` (396-397): fused into
+            else:                                  # the norm that follows it, below
                 c0, n_chunks = _chunk_run(self.batch_idx)
                 if n_frames % n_chunks:
                     raise ValueError(f"{n_frames} frames per branch do not split into {n_chunks} chunks")
@@ -460,16 +475,26 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
                                                          resid, out_dtype)
 
             if self.attn2 is not None:
-                norm_hidden_states = (
-                    self.norm2(hidden_states, timestep) if self.use_ada_layer_norm
-                    else _block_norm(self.norm2, hidden_states, which="norm2")[0])
-                attn_output = self.attn2(norm_hidden_states, encoder_hidden_states=encoder_hidden_states,
-                                         attention_mask=encoder_attention_mask, **cross_attention_kwargs)
-                hidden_states = attn_output + hidden_states
+                if self.use_ada_layer_norm:
+                    if pending is not None:
+                        hidden_states, pending = pending + hidden_states, None
+                    norm_hidden_states = self.norm2(hidden_states, timestep)
+                elif pending is not None:
+                    hidden_states, norm_hidden_states = _add_norm(self.norm2, pending, hidden_states, "norm2")
+                    pending = None
+                else:
+                    norm_hidden_states = _block_norm(self.norm2, hidden_states, which="norm2")[0]
+                pending = self.attn2(norm_hidden_states, encoder_hidden_states=encoder_hidden_states,
+                                     attention_mask=encoder_attention_mask, **cross_attention_kwargs)   # + hidden_states (411)
 
             if self.use_ada_layer_norm_zero:    # the modulation consumes the fp32 norm output: keep the module
+                if pending is not None:
+                    hidden_states, pending = pending + hidden_states, None
                 norm_hidden_states = self.norm3(hidden_states)
                 norm_hidden_states = norm_hidden_states * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
+            elif pending is not None:
+                hidden_states, norm_hidden_states = _add_norm(self.norm3, pending, hidden_states, "norm3")
+                pending = None
             else:
                 norm_hidden_states = _block_norm(self.norm3, hidden_states, which="norm3")[0]
             ff_output = self.ff(norm_hidden_states)

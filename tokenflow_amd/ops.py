@@ -287,6 +287,31 @@ def layer_norm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[t
     return out, inv
 
 
+def add_layer_norm(a: torch.Tensor, b: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
+                   eps: float, out_dtype: torch.dtype):
+    """(a + b, LayerNorm(a + b)) in one pass (tf_add_layer_norm): the sum has torch's promoted dtype and rounding, the
+    norm is `layer_norm` of that rounded sum -- bit-identical to the two separate ops."""
+    dev = _need_gpu(a, b, weight, bias)
+    lib = _lib.load()
+    if a.shape != b.shape:
+        raise ValueError("add_layer_norm: a and b must have one shape")
+    a, b = a.contiguous(), b.contiguous()
+    D = a.shape[-1]
+    rows = a.numel() // D
+    if weight is not None and bias is not None and weight.dtype != bias.dtype:
+        bias = bias.to(weight.dtype)
+    wt = weight if weight is not None else bias
+    weight = weight.contiguous() if weight is not None else None
+    bias = bias.contiguous() if bias is not None else None
+    total = torch.empty(a.shape, dtype=torch.promote_types(a.dtype, b.dtype), device=a.device)
+    out = torch.empty(a.shape, dtype=out_dtype, device=a.device)
+    _launch(dev, "tf_add_layer_norm", lib.tf_add_layer_norm, a.data_ptr(), b.data_ptr(), total.data_ptr(),
+            weight.data_ptr() if weight is not None else 0, bias.data_ptr() if bias is not None else 0, out.data_ptr(),
+            rows, D, float(eps), _DT[a.dtype], _DT[b.dtype], _DT[total.dtype], _DT[wt.dtype] if wt is not None else 0,
+            _DT[out_dtype])
+    return total, out
+
+
 def propagate(tgt: torch.Tensor, piv: torch.Tensor, inv_norm: torch.Tensor, kf_ids: Sequence[int],
               kf_out: torch.Tensor, w: Optional[torch.Tensor], n: int, residual: Optional[torch.Tensor],
               out_dtype: torch.dtype) -> torch.Tensor:
