@@ -222,7 +222,7 @@ def test_hooks_16bit_block_uses_fused_norm_and_matches_module_norm():
     # (pivotal: norm2, norm3; propagation: norm3 -- its self-attention residual is added by the gather kernel)
     assert len(calls) == 3 and len(add_calls) == 3
     keep = hooks._fused_norm_dtype
-    hooks._fused_norm_dtype = lambda mod, x: None
+    hooks._fused_norm_dtype = lambda mod, x, in_dtype=None: None
     try:
         plain = run()
     finally:
