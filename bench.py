@@ -29,6 +29,10 @@ Prints ONE JSON line (rank 0):
                 (profiles/traffic.json; collected separately, never in this run) or null.
   parity        in-run check against the oracle (after the timed region, rank 0, N = 1): max |out - ref| of the
                 level-0 attention on sampled rows, and the tie-aware NN index mismatch rate of a level-0 chunk.
+  yardstick     same box, same run, after the timed region (rank 0, N = 1): what the vendor libraries reach -- hipBLASLt
+                (torch.matmul, bf16 8192^3) and PyTorch-ROCm's fused attention (aotriton flash behind
+                scaled_dot_product_attention) on the level-0 bank problems.  Comparison points for the roofline
+                fraction, never part of the product path.
   cpu_baseline  the CPU oracle ("port" of the reference hook path, fp32 torch CPU, the reference's own
                 bmm -> *scale -> softmax -> bmm structure) timed on this box's host cores on a bounded sample.
 """
@@ -69,6 +73,7 @@ def parse():
                          "separate eager pass after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-yardstick", action="store_true")
     ap.add_argument("--cpu-sample-levels", default="0,1,2,3")
     return ap.parse_args()
 
@@ -159,6 +164,48 @@ def usable_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def yardstick(cfg):
+    """Vendor-library comparison points measured on this box right after the timed region (SURVEY.md appendix C:
+    SDPA 'as a yardstick only').  torch ops on purpose -- nothing here is on the product path."""
+    import torch.nn.functional as F
+
+    def timed(fn, reps):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    res = {}
+    g = torch.Generator(device="cuda").manual_seed(7)
+    try:
+        a = torch.randn(8192, 8192, generator=g, device="cuda").bfloat16()
+        b = torch.randn(8192, 8192, generator=g, device="cuda").bfloat16()
+        ms = timed(lambda: torch.matmul(a, b), 20)
+        res["hipblaslt_gemm_bf16_8192_tflops"] = round(2.0 * 8192 ** 3 / ms / 1e9, 1)
+        del a, b
+    except Exception as e:  # noqa: BLE001
+        res["hipblaslt_gemm_bf16_8192_tflops"] = None
+        res["gemm_error"] = str(e)[:120]
+    try:
+        S, D, h = cfg.levels[0]
+        K, d = cfg.K, D // h
+        q, k, v = (torch.randn(2, h, K * S, d, generator=g, device="cuda").bfloat16() for _ in range(3))
+        with torch.nn.attention.sdpa_kernel(torch.nn.attention.SDPBackend.FLASH_ATTENTION):
+            ms = timed(lambda: F.scaled_dot_product_attention(q, k, v), 3)
+        res["torch_sdpa_flash_level0_bank_tflops"] = round(4.0 * 2 * K * S * K * S * D / ms / 1e9, 1)
+        res["torch_sdpa_note"] = ("uncond + cond bank problems of level 0 (head dim %d) on head-major copies made "
+                                  "outside the timed bracket" % d)
+    except Exception as e:  # noqa: BLE001
+        res["torch_sdpa_flash_level0_bank_tflops"] = None
+        res["sdpa_error"] = str(e)[:120]
+    return res
 
 
 def cpu_baseline(cfg, levels):
@@ -415,6 +462,8 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_parity:
             out["parity"] = parity_check(cfg, blocks, w)
+        if world == 1 and not args.no_yardstick:
+            out["yardstick"] = yardstick(cfg)
         if world == 1 and not args.no_cpu_baseline:
             lv = [int(x) for x in args.cpu_sample_levels.split(",") if x != ""]
             out["cpu_baseline"] = cpu_baseline(cfg, lv)

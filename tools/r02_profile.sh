@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; mkdir -p $O
 python $R/bench.py --steps 10 --warmup 3 > $O/bench.json 2> $O/bench.err
-rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats -d /tmp/kt -- python $R/bench.py --no-cpu-baseline --no-parity --steps 8 --warmup 2 > $O/bench_traced.json 2>/dev/null
+rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats -d /tmp/kt -- python $R/bench.py --no-cpu-baseline --no-parity --no-yardstick --steps 8 --warmup 2 > $O/bench_traced.json 2>/dev/null
 python $R/tools/rocpd_stats.py $(find /tmp/kt -name "*_results.db" | head -1) > $O/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   rm -rf /tmp/pmc_$c; rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -- python $R/tools/attn_microbench.py 8,4096,8,40 > /dev/null 2>&1
@@ -21,7 +21,7 @@ python $R/tools/nn_microbench.py > $O/nn_microbench.txt 2>&1
 python $R/tools/rank_pivotal_microbench.py 8 > $O/rank_pivotal.txt 2>&1
 for cfg in cfg1 cfg4 cfg5; do python $R/bench.py --config $cfg --no-cpu-baseline --steps 3 --warmup 1 > $O/bench_$cfg.json 2>$O/bench_$cfg.err; done
 python $R/bench.py --config cfg1 --no-cpu-baseline --steps 50 --warmup 5 --graph > $O/bench_cfg1_graph.json 2>>$O/bench_cfg1.err
-python $R/bench.py --no-cpu-baseline --no-parity --steps 10 --warmup 3 --per-chunk > $O/bench_per_chunk.json 2>/dev/null
+python $R/bench.py --no-cpu-baseline --no-parity --no-yardstick --steps 10 --warmup 3 --per-chunk > $O/bench_per_chunk.json 2>/dev/null
 for a in "" "--graph" "--graph --all-chunks" "--proj" "--proj --graph"; do python $R/tools/hooks_bench.py cfg2 6 $a >> $O/hooks_bench.txt 2>/dev/null; done
 python $R/tools/hooks_bench.py cfg1 20 >> $O/hooks_bench.txt 2>/dev/null; python $R/tools/hooks_bench.py cfg1 20 --graph >> $O/hooks_bench.txt 2>/dev/null
 ls -la $O

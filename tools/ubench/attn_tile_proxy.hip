@@ -1,0 +1,160 @@
+// Proxy of the level-0 attention inner loop (head dim 40, one 32-query x 64-key tile per wave and iteration), run
+// long enough (hundreds of ms) on toggling data for the board's power management to settle -- the real kernel is
+// power-limited (tools/clock_probe.py: 1.87 GHz at 1.2 kW).  Question: same matrix-pipe cycles (448 per tile) issued
+// as v_mfma_f32_16x16x32_bf16 instead of v_mfma_f32_32x32x16_bf16 -- does the lower accumulator traffic of the small
+// shape buy clock?  (tools/ubench/mfma_shapes rand: bare MFMAs run 2.21 vs 1.89 PFLOP/s.)
+//   SHAPE 0: S^T = K Q^T as 2 x 3 MFMAs 32x32x16 (K = 48), O^T += V^T P as 2 x 4 (M = 64)          -> 14 x 32 cycles
+//   SHAPE 1: S^T as 4 x 2 x 2 MFMAs 16x16x32 (K = 64), O^T as 3 x 2 x 2 (M = 48)                    -> 28 x 16 cycles
+// Both read 14 fragments of 1 KiB from LDS per tile and run the same softmax mix (16 pk_fma, 32 exp2, 16 cvt_pk).
+// No global loads, LDS writes or barriers in the loop.
+//   hipcc --offload-arch=gfx950 -O3 -o attn_tile_proxy attn_tile_proxy.hip && ./attn_tile_proxy
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    bf16x2 r = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, r);
+}
+
+template <int SHAPE>
+__global__ __launch_bounds__(512) void k(const u32x4* __restrict__ src, float* out, int iters) {
+    __shared__ u32x4 lds[2 * 16 * 64];   // two images of 16 fragments x 64 lanes x 16 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 2 * 16 * 64; i += 512) lds[i] = src[i];
+    __syncthreads();
+    const float c = 0.11f, m = 8.f;
+    bf16x8 q[4];
+    for (int t = 0; t < 4; ++t) q[t] = __builtin_bit_cast(bf16x8, src[(t * 64 + lane + tid) & 2047]);
+    if (SHAPE == 0) {
+        f32x16 o0, o1;
+        for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+            int off = (it & 1) * 1024 + lane;
+            asm volatile("" : "+v"(off));
+            const u32x4* f = lds + off;
+            f32x16 s0, s1;
+            for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[(2 * t) * 64]), q[t], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[(2 * t + 1) * 64]), q[t], s1, 0, 0, 0);
+            }
+            u32x4 p[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned w[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int r = 4 * (g & 1) * 2 + 2 * (h & 1) + 4 * (h >> 1);   // any fixed 2 of the 16 scores
+                    const f32x16& s = g < 2 ? s0 : s1;
+                    const f32x2 x = f32x2{s[r], s[r + 1]} * c - m;
+                    w[h] = pack2(__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1]));
+                }
+                p[g] = u32x4{w[0], w[1], w[2], w[3]};
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[(6 + 2 * g) * 64]),
+                                                             __builtin_bit_cast(bf16x8, p[g]), o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[(7 + 2 * g) * 64]),
+                                                             __builtin_bit_cast(bf16x8, p[g]), o1, 0, 0, 0);
+            }
+        }
+        float s = 0.f;
+        for (int r = 0; r < 16; ++r) s += o0[r] + o1[r];
+        out[blockIdx.x * 512 + tid] = s;
+    } else {
+        f32x4 o[3][2];
+        for (int d = 0; d < 3; ++d)
+            for (int t = 0; t < 2; ++t) o[d][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) {
+            int off = (it & 1) * 1024 + lane;
+            asm volatile("" : "+v"(off));
+            const u32x4* f = lds + off;
+            f32x4 s[4][2];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const bf16x8 k0 = __builtin_bit_cast(bf16x8, f[(2 * kt) * 64]);
+                const bf16x8 k1 = __builtin_bit_cast(bf16x8, f[(2 * kt + 1) * 64]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    s[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q[2 * t], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    s[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, q[2 * t + 1], s[kt][t], 0, 0, 0);
+                }
+            }
+            u32x4 p[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    unsigned w[4];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const f32x4& sv = s[2 * j + (h >> 1)][t];
+                        const f32x2 x = f32x2{sv[2 * (h & 1)], sv[2 * (h & 1) + 1]} * c - m;
+                        w[h] = pack2(__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1]));
+                    }
+                    p[j][t] = u32x4{w[0], w[1], w[2], w[3]};
+                }
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8 v = __builtin_bit_cast(bf16x8, f[(8 + 2 * d + j) * 64]);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        o[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v, __builtin_bit_cast(bf16x8, p[j][t]), o[d][t], 0, 0, 0);
+                }
+        }
+        float sm = 0.f;
+        for (int d = 0; d < 3; ++d)
+            for (int t = 0; t < 2; ++t)
+                for (int r = 0; r < 4; ++r) sm += o[d][t][r];
+        out[blockIdx.x * 512 + tid] = sm;
+    }
+}
+
+template <int SHAPE>
+float run(const u32x4* src, float* out, int iters) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((k<SHAPE>), dim3(512), dim3(512), 0, 0, src, out, 100);
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((k<SHAPE>), dim3(512), dim3(512), 0, 0, src, out, iters);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+}
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 200000;
+    unsigned short* h = (unsigned short*)malloc(2048 * 16);
+    unsigned x = 12345u;
+    for (int i = 0; i < 2048 * 8; ++i) {
+        x = x * 1664525u + 1013904223u;
+        h[i] = (unsigned short)(((x >> 16) & 0x80ff) | 0x3f00);   // bf16 in +-[0.5, 2): sign, exponent 126/127, mantissa
+    }
+    u32x4* src;
+    float* out;
+    (void)hipMalloc(&src, 2048 * 16);
+    (void)hipMemcpy(src, h, 2048 * 16, hipMemcpyHostToDevice);
+    (void)hipMalloc(&out, 512 * 512 * 4);
+    for (int rep = 0; rep < 2; ++rep) {
+        const float t0 = run<0>(src, out, iters), t1 = run<1>(src, out, iters);
+        const double tiles = (double)iters * 512 * 8;                 // wave-tiles
+        const double fl = tiles * 2.0 * 2 * 32 * 64 * 40;             // algorithmic flops at head dim 40
+        printf("4 waves/SIMD, %d tiles per wave: 32x32x16 %.1f ms = %.0f TF/s (algorithmic) | 16x16x32 %.1f ms = %.0f TF/s\n",
+               iters, t0, fl / t0 / 1e9, t1, fl / t1 / 1e9);
+    }
+    return 0;
+}

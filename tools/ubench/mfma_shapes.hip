@@ -53,13 +53,25 @@ float run(const bf16x8* a, float* out, int block, int iters) {
     return ms;
 }
 
-int main() {
+// `./mfma_shapes rand`: operands = pseudo-random bf16 in (-2, 2) instead of one repeated value -- the same
+// instruction stream on toggling data shows how far the board's power limit pulls the clock (and the rate) down.
+int main(int argc, char** argv) {
     bf16x8* a;
     float* out;
     hipMalloc(&a, 128 * sizeof(bf16x8));
     hipMemset(a, 0x3c, 128 * sizeof(bf16x8));
+    if (argc > 1) {
+        unsigned short h[128 * 8];
+        unsigned x = 12345u;
+        for (int i = 0; i < 128 * 8; ++i) {
+            x = x * 1664525u + 1013904223u;
+            h[i] = (unsigned short)(((x >> 16) & 0x80ff) | 0x3f00);   // sign, exponent 126/127, random mantissa
+        }
+        hipMemcpy(a, h, sizeof(h), hipMemcpyHostToDevice);
+        printf("operands: pseudo-random bf16\n");
+    }
     hipMalloc(&out, 256 * 1024 * 4);
-    const int iters = 20000;
+    const int iters = argc > 1 ? 200000 : 20000;
     const char* names[4] = {"32x32x16", "16x16x32", "32x32x8_1k", "16x16x16_1k"};
     const double macs[4] = {32. * 32 * 16, 16. * 16 * 32, 32. * 32 * 8, 16. * 16 * 16};
     for (int block : {256, 512}) {
