@@ -57,6 +57,47 @@ __device__ __forceinline__ void store8(T* p, const float (&f)[8]) {
     }
 }
 
+// Streaming accesses of the kernel (residual in, result out) are touched exactly once: nontemporal, so that they
+// do not push the keyframe rows -- every one of them gathered ~2 n times per block -- out of the L2
+// (-2 % at cfg2 levels 0 and 1, profiles/r02_gather_order_ab.txt).
+template <typename T>
+__device__ __forceinline__ void load8_stream(const T* p, float (&f)[8]) {
+    if constexpr (sizeof(T) == 4) {
+        const u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+        const u32x4 b = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[i] = __uint_as_float(a[i]);
+            f[4 + i] = __uint_as_float(b[i]);
+        }
+    } else {
+        typedef T v8 __attribute__((ext_vector_type(8)));
+        const v8 v = __builtin_bit_cast(v8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store8_stream(T* p, const float (&f)[8]) {
+    if constexpr (sizeof(T) == 4) {
+        u32x4 a, b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i] = __float_as_uint(f[i]);
+            b[i] = __float_as_uint(f[4 + i]);
+        }
+        __builtin_nontemporal_store(a, reinterpret_cast<u32x4*>(p));
+        __builtin_nontemporal_store(b, reinterpret_cast<u32x4*>(p + 4));
+    } else {
+        typedef T v8 __attribute__((ext_vector_type(8)));
+        v8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (T)f[i];  // round-to-nearest-even
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p));
+    }
+}
+
 struct NoRes {};
 
 // Multi-chunk call (tf_nn_gather_blend_chunks): `n` frames are C chunks of nc frames; chunk j = frame / nc gathers
@@ -124,7 +165,7 @@ __global__ __launch_bounds__(256) void gather_blend_kernel(const TIn* __restrict
             const int64_t off = b * branch_out + t * D + c;
             if constexpr (!__is_same(TRes, NoRes)) {
                 float h[8];
-                load8(resid + off, h);
+                load8_stream(resid + off, h);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = __fadd_rn(o[i], h[i]);
             }
@@ -135,7 +176,7 @@ __global__ __launch_bounds__(256) void gather_blend_kernel(const TIn* __restrict
                         o[i] = ch.single_dtype == TF_BF16 ? (float)(__bf16)o[i] : (float)(_Float16)o[i];
                 }
             }
-            store8(out + off, o);
+            store8_stream(out + off, o);
         }
     }
 }
