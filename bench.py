@@ -166,6 +166,37 @@ def usable_cores():
     return n
 
 
+def power_state(blocks):
+    """Shader clock and socket power while the dominant kernel runs: replay the level-0 plain attention for ~0.6 s
+    (enqueued asynchronously) and read `rocm-smi` once in the middle.  On this box the launch is power-limited
+    (~1.87 GHz at ~1.2 kW against 2.4 GHz nominal), which is what this records next to `roofline`."""
+    import re
+    import subprocess
+    blk = next(b for b in blocks if b.lvl == 0)
+    d = blk.D // blk.h
+    fn = lambda: ops.ext_attn(blk.q, blk.k, blk.v, blk.h, d ** -0.5, False)  # noqa: E731
+    try:
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        one = time.perf_counter() - t0
+        for _ in range(max(4, int(1.5 / max(one, 1e-4)))):
+            fn()
+        time.sleep(0.3)
+        txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True,
+                             timeout=30).stdout
+        torch.cuda.synchronize()
+        sclk = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", txt)
+        pw = re.search(r"Power \(W\): ([0-9.]+)", txt)
+        return {"kernel": "level-0 attention, no injection, replayed back to back", "sclk_mhz": sclk and int(sclk.group(1)),
+                "socket_power_w": pw and float(pw.group(1)), "nominal_sclk_mhz": 2400, "source": "rocm-smi, one sample mid-replay"}
+    except Exception as e:  # noqa: BLE001
+        torch.cuda.synchronize()
+        return {"error": str(e)[:120]}
+
+
 def yardstick(cfg):
     """Vendor-library comparison points measured on this box right after the timed region (SURVEY.md appendix C:
     SDPA 'as a yardstick only').  torch ops on purpose -- nothing here is on the product path."""
@@ -464,6 +495,7 @@ def main():
             out["parity"] = parity_check(cfg, blocks, w)
         if world == 1 and not args.no_yardstick:
             out["yardstick"] = yardstick(cfg)
+            out["yardstick"]["power_state"] = power_state(blocks)
         if world == 1 and not args.no_cpu_baseline:
             lv = [int(x) for x in args.cpu_sample_levels.split(",") if x != ""]
             out["cpu_baseline"] = cpu_baseline(cfg, lv)
