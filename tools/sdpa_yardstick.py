@@ -41,5 +41,24 @@ def main():
                 print(f"K={K} S={S} h={h} d={d}: torch SDPA[{name}] unavailable: {str(e)[:80]}", flush=True)
 
 
+def nn_gemm():
+    """The NN search of one cfg2 level-0 chunk as a PLAIN GEMM through hipBLASLt: [n*S, D] x [D, 2*S] -> the bf16
+    similarity matrix the reference materialises (335 MB), no normalisation, no argmax -- next to tf_nn_search."""
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for K, n, S, D in [(8, 5, 4096, 320), (8, 5, 1024, 640), (10, 8, 9216, 320)]:
+        ln = torch.nn.functional.layer_norm
+        piv = ln(torch.randn(K, S, D, generator=g, device="cuda"), (D,)).bfloat16()
+        tgt = ln(torch.randn(n * S, D, generator=g, device="cuda"), (D,)).bfloat16()
+        inv = ops.pivot_inv_norm(piv)
+        y = piv[2:4].reshape(2 * S, D)
+        fl = 2.0 * n * S * 2 * S * D
+        t_gemm, _ = time_it(lambda: torch.matmul(tgt, y.T), reps=10)
+        t_ours, _ = time_it(lambda: ops.nn_search(tgt, piv, inv, [3, 2]), reps=10)
+        print(f"NN chunk n={n} S={S} D={D}: torch.matmul (hipBLASLt, writes the similarity matrix) {t_gemm * 1e3:.1f} us = "
+              f"{fl / t_gemm / 1e9:.0f} TF/s | tf_nn_search (fused normalisation + argmax) {t_ours * 1e3:.1f} us = "
+              f"{fl / t_ours / 1e9:.0f} TF/s", flush=True)
+
+
 if __name__ == "__main__":
     main()
+    nn_gemm()
