@@ -52,6 +52,7 @@ extern "C" {
 #define TF_ERR_SHAPE (-3)
 #define TF_ERR_ALIGN (-4)
 #define TF_ERR_WORKSPACE (-5)
+#define TF_ERR_COMM (-6)      /* RCCL not loadable, or a collective failed (tf_last_error has RCCL's message) */
 
 int tf_abi_version(void);
 
@@ -262,6 +263,38 @@ int tf_ddim_step(const void* x, const void* eps, void* out, int64_t n, float mu_
  * elem_bytes = bytes per element; elems_per_branch*elem_bytes multiple of 16.
  * ------------------------------------------------------------------------ */
 int tf_inject_copy(void* x, int64_t elems_per_branch, int elem_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Multi-GPU exchange steps over RCCL (one process per GPU).  The reference is single-process (no
+ * parallelism of any kind), so these replace nothing in it; they are the C-ABI form of the two exchange steps of
+ * tokenflow_amd/sharded.py for hosts that do not go through torch.distributed (the Python host does, and never calls
+ * these).  Frames are sharded over the ranks:
+ *   pivotal pass  (tokenflow_utils.py:133-138: every keyframe's queries read the keys/values of ALL K keyframes)
+ *       tf_allgather_kv      each rank contributes its keyframes' slab, all ranks receive the bank (equal slabs), or
+ *       tf_all_to_all_rows   frames <-> heads re-sharding: rows [send_rows[p]] to peer p, [recv_rows[p]] from peer p
+ *                            (row = row_elems elements; send / recv buffers are the concatenation in peer order);
+ *   propagation   (331-333: chunk c reads keyframes c and c-1)
+ *       tf_sendrecv_pivot    the last local keyframe's pivot features / inverse norms / attention output go to
+ *                            send_peer (rank + 1) while the left neighbour's arrive from recv_peer (rank - 1);
+ *                            a peer of -1 skips that direction (first / last rank).
+ * Exceptions to the conventions at the top, all of them RCCL's: tf_comm_init / tf_comm_destroy allocate and free the
+ * communicator handle and may synchronise; RCCL (librccl.so.1) is dlopen-ed on the first tf_comm_* call -- inside a
+ * PyTorch process that is the copy torch has loaded -- and TF_ERR_COMM is returned if it is absent.  The collectives
+ * themselves are asynchronous on `stream` like every other entry point.  tf_comm_init binds the calling thread's
+ * current device (hipSetDevice first).  The unique id (128 bytes) is created on one rank by tf_comm_unique_id and
+ * handed to the others by the host (file, socket, MPI ...).
+ * ------------------------------------------------------------------------ */
+typedef struct tf_comm tf_comm;
+int tf_comm_unique_id(void* id_out_128_bytes);
+int tf_comm_init(const void* unique_id_128_bytes, int rank, int world, tf_comm** comm_out);
+int tf_comm_destroy(tf_comm* comm);
+int tf_comm_rank(const tf_comm* comm);
+int tf_comm_world(const tf_comm* comm);
+int tf_allgather_kv(tf_comm* comm, const void* local, void* bank, int64_t elems_per_rank, int dtype, void* stream);
+int tf_all_to_all_rows(tf_comm* comm, const void* send, void* recv, const int64_t* send_rows, const int64_t* recv_rows,
+                       int64_t row_elems, int dtype, void* stream);
+int tf_sendrecv_pivot(tf_comm* comm, const void* const* send, const int64_t* send_elems, int n_send, int send_peer,
+                      void* const* recv, const int64_t* recv_elems, int n_recv, int recv_peer, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

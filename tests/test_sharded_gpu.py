@@ -143,3 +143,82 @@ def test_head_exchange_through_rccl_single_rank():
     ret = mgr.dict()
     mp.spawn(_rccl_worker, args=(port, ret), nprocs=1, join=True)
     assert dict(ret) == {0: True}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The C-ABI exchange steps (tf_comm_*, include/tokenflow_hip.h) through tokenflow_amd.comm: RCCL bound by dlopen.
+
+def test_c_abi_comm_single_rank():
+    """World of one on the real backend: every entry point runs (communicator, all-gather, row all-to-all, grouped
+    send/recv with itself) and moves the bytes it should."""
+    from tokenflow_amd import comm
+    c = comm.HipComm(comm.HipComm.unique_id(), 0, 1)
+    try:
+        g = torch.Generator(device="cuda").manual_seed(3)
+        for dt in (torch.bfloat16, torch.float16, torch.float32):
+            a = torch.randn(5, 64, 40, generator=g, device="cuda").to(dt)
+            bank = torch.empty_like(a)
+            assert torch.equal(c.allgather(a, bank), a)
+            r = torch.empty_like(a)
+            assert torch.equal(c.all_to_all_rows(a, r, [5], [5]), a)
+            r2 = torch.empty_like(a)
+            assert torch.equal(c.all_to_all_rows(a, r2), a)                 # equal parts
+        s1, s2 = torch.randn(64, 320, generator=g, device="cuda").bfloat16(), torch.randn(64, generator=g, device="cuda").bfloat16()
+        d1, d2 = torch.zeros_like(s1), torch.zeros_like(s2)
+        c.sendrecv([s1, s2], 0, [d1, d2], 0)
+        c.sendrecv([s1], -1, [d1], -1)                                       # both directions skipped: no-op
+        torch.cuda.synchronize()
+        assert torch.equal(d1, s1) and torch.equal(d2, s2)
+        with pytest.raises(ValueError):
+            c.all_to_all_rows(s1, torch.empty(3, 320, device="cuda", dtype=torch.bfloat16), [64], [2])
+    finally:
+        c.close()
+
+
+def _comm_worker(rank, world, path, ret):
+    import time
+    from tokenflow_amd import comm
+    torch.cuda.set_device(rank)
+    if rank == 0:
+        uid = comm.HipComm.unique_id()
+        with open(path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.replace(path + ".tmp", path)
+    else:
+        while not os.path.exists(path):
+            time.sleep(0.01)
+        uid = open(path, "rb").read()
+    c = comm.HipComm(uid, rank, world)
+    try:
+        dev = torch.device("cuda", rank)
+        S, D = 64, 80
+        mine = torch.full((2, S, D), float(rank + 1), device=dev).bfloat16()
+        bank = torch.empty(world * 2, S, D, device=dev, dtype=torch.bfloat16)
+        c.allgather(mine, bank)
+        ok = all(bool((bank[2 * r:2 * r + 2] == r + 1).all()) for r in range(world))
+        # uneven rows: rank r sends (p + 1) rows to peer p, so it receives (r + 1) rows from everybody
+        send_rows = [p + 1 for p in range(world)]
+        recv_rows = [rank + 1] * world
+        send = torch.cat([torch.full((p + 1, D), 10.0 * rank + p, device=dev) for p in range(world)]).bfloat16()
+        recv = torch.empty(sum(recv_rows), D, device=dev, dtype=torch.bfloat16)
+        c.all_to_all_rows(send, recv, send_rows, recv_rows)
+        off = 0
+        for p in range(world):
+            ok = ok and bool((recv[off:off + rank + 1] == 10.0 * p + rank).all())
+            off += rank + 1
+        # halo: last keyframe to rank + 1, the left neighbour's from rank - 1
+        halo = torch.zeros(S, D, device=dev, dtype=torch.bfloat16)
+        c.sendrecv([mine[-1]], rank + 1 if rank + 1 < world else -1, [halo], rank - 1 if rank > 0 else -1)
+        torch.cuda.synchronize()
+        ok = ok and bool((halo == (rank if rank > 0 else 0)).all())
+        ret[rank] = ok
+    finally:
+        c.close()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_c_abi_comm_two_gpus(tmp_path):
+    ret = mp.get_context("spawn").Manager().dict()
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    mp.spawn(_comm_worker, args=(2, str(tmp_path / "uid"), ret), nprocs=2, join=True)
+    assert ret[0] and ret[1]

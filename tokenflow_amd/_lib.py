@@ -11,6 +11,7 @@ TF_ATTN_INJECT, TF_ATTN_EXACT_SCALE, TF_ATTN_BANK_ONLY, TF_ATTN_SOURCE_ONLY, TF_
 TF_ATTN_OUT_F32 = 32
 TF_ATTN_FOLD_SCALE = 64
 ABI_VERSION = 2
+TF_ERR_COMM = -6
 
 _c = ctypes
 _SIGNATURES = {
@@ -39,6 +40,16 @@ _SIGNATURES = {
     "tf_add_layer_norm": (_c.c_int, [_c.c_void_p] * 6 + [_c.c_int64, _c.c_int, _c.c_float] + [_c.c_int] * 5 + [_c.c_void_p]),
     "tf_ddim_step": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_int64] + [_c.c_float] * 4 + [_c.c_int, _c.c_void_p]),
     "tf_inject_copy": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p]),
+    # multi-GPU exchange steps over RCCL (tokenflow_amd/comm.py; the sharded host path uses torch.distributed instead)
+    "tf_comm_unique_id": (_c.c_int, [_c.c_void_p]),
+    "tf_comm_init": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p]),
+    "tf_comm_destroy": (_c.c_int, [_c.c_void_p]),
+    "tf_comm_rank": (_c.c_int, [_c.c_void_p]),
+    "tf_comm_world": (_c.c_int, [_c.c_void_p]),
+    "tf_allgather_kv": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p]),
+    "tf_all_to_all_rows": (_c.c_int, [_c.c_void_p] * 5 + [_c.c_int64, _c.c_int, _c.c_void_p]),
+    "tf_sendrecv_pivot": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                     _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -1,0 +1,107 @@
+"""RCCL exchange steps through the library's own C ABI (`tf_comm_*`, include/tokenflow_hip.h) -- for hosts that do not
+use torch.distributed.  `tokenflow_amd.sharded.FrameShard`, the host path this package ships and measures, runs the
+same two exchange steps through torch.distributed (backend "nccl" = RCCL); this module is the ctypes binding of the
+entry points SURVEY.md section 8b lists for a native host, and what the GPU tests drive them through.
+
+One process per GPU:
+
+    uid = HipComm.unique_id() on rank 0, handed to the other ranks by the host (file, socket, ...)
+    comm = HipComm(uid, rank, world)              # binds the current device
+    comm.allgather(local, bank)                   # K/V bank of the pivotal pass (tokenflow_utils.py:133-138)
+    comm.all_to_all_rows(send, recv, send_rows, recv_rows)      # frames <-> heads re-sharding
+    comm.sendrecv([piv_last, inv_last, ...], rank + 1, [piv_halo, inv_halo, ...], rank - 1)   # 331-333
+
+All calls are asynchronous on the current torch stream.  The reference is single-process; nothing here replaces a line
+of it."""
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+
+_DT = {torch.bfloat16: _lib.TF_BF16, torch.float16: _lib.TF_F16, torch.float32: _lib.TF_F32}
+
+
+def _stream(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _dev(*ts: torch.Tensor) -> int:
+    for t in ts:
+        if not t.is_cuda:
+            raise _lib.TokenflowHipError("tokenflow_amd.comm: tensors must live on the GPU (there is no CPU path)")
+        if not t.is_contiguous():
+            raise ValueError("tokenflow_amd.comm: tensors must be contiguous")
+    if len({t.dtype for t in ts}) != 1 or ts[0].dtype not in _DT:
+        raise TypeError("tokenflow_amd.comm: one of bf16 / f16 / f32 for all tensors of a call")
+    return _DT[ts[0].dtype]
+
+
+class HipComm:
+    def __init__(self, unique_id: bytes, rank: int, world: int):
+        if len(unique_id) != 128:
+            raise ValueError("unique_id: 128 bytes from HipComm.unique_id()")
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(unique_id, 128)
+        _lib.check(lib.tf_comm_init(buf, rank, world, ctypes.byref(h)), "tf_comm_init")
+        self._h, self.rank, self.world = h, rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.load().tf_comm_unique_id(buf), "tf_comm_unique_id")
+        return buf.raw
+
+    def close(self):
+        if self._h is not None:
+            h, self._h = self._h, None
+            _lib.check(_lib.load().tf_comm_destroy(h), "tf_comm_destroy")
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    def allgather(self, local: torch.Tensor, bank: torch.Tensor):
+        """bank [world * local.numel()] <- every rank's `local`, in rank order."""
+        dt = _dev(local, bank)
+        if bank.numel() != self.world * local.numel():
+            raise ValueError(f"bank has {bank.numel()} elements, expected {self.world} x {local.numel()}")
+        _lib.check(_lib.load().tf_allgather_kv(self._h, local.data_ptr(), bank.data_ptr(), local.numel(), dt,
+                                               _stream(local)), "tf_allgather_kv")
+        return bank
+
+    def all_to_all_rows(self, send: torch.Tensor, recv: torch.Tensor, send_rows: Optional[Sequence[int]] = None,
+                        recv_rows: Optional[Sequence[int]] = None):
+        """send [sum(send_rows), ...] -> rows send_rows[p] to peer p; recv [sum(recv_rows), ...] <- recv_rows[p] rows
+        from peer p (None = equal parts), like dist.all_to_all_single over dim 0."""
+        dt = _dev(send, recv)
+        W = self.world
+        send_rows = list(send_rows) if send_rows is not None else [send.shape[0] // W] * W
+        recv_rows = list(recv_rows) if recv_rows is not None else [recv.shape[0] // W] * W
+        row = send[0].numel() if send.shape[0] else recv[0].numel()
+        if len(send_rows) != W or len(recv_rows) != W or sum(send_rows) != send.shape[0] or \
+                sum(recv_rows) != recv.shape[0] or (recv.shape[0] and recv[0].numel() != row):
+            raise ValueError("all_to_all_rows: row counts do not match the buffers")
+        sr, rr = (ctypes.c_int64 * W)(*send_rows), (ctypes.c_int64 * W)(*recv_rows)
+        _lib.check(_lib.load().tf_all_to_all_rows(self._h, send.data_ptr(), recv.data_ptr(), sr, rr, row, dt,
+                                                  _stream(send)), "tf_all_to_all_rows")
+        return recv
+
+    def sendrecv(self, send: Sequence[torch.Tensor], send_peer: int, recv: Sequence[torch.Tensor], recv_peer: int):
+        """`send` tensors to send_peer while `recv` tensors arrive from recv_peer, one grouped exchange; a peer of -1
+        skips that direction."""
+        ts = list(send if send_peer >= 0 else []) + list(recv if recv_peer >= 0 else [])
+        if not ts:
+            return
+        dt = _dev(*ts)
+        ns, nr = (len(send) if send_peer >= 0 else 0), (len(recv) if recv_peer >= 0 else 0)
+        sp = (ctypes.c_void_p * max(ns, 1))(*[t.data_ptr() for t in send[:ns]])
+        se = (ctypes.c_int64 * max(ns, 1))(*[t.numel() for t in send[:ns]])
+        rp = (ctypes.c_void_p * max(nr, 1))(*[t.data_ptr() for t in recv[:nr]])
+        re_ = (ctypes.c_int64 * max(nr, 1))(*[t.numel() for t in recv[:nr]])
+        _lib.check(_lib.load().tf_sendrecv_pivot(self._h, sp, se, ns, send_peer, rp, re_, nr, recv_peer, dt,
+                                                 _stream(ts[0])), "tf_sendrecv_pivot")

@@ -1,0 +1,175 @@
+// Multi-GPU exchange steps of the hot path over RCCL, for hosts that do not go through torch.distributed
+// (tf_comm_init / tf_allgather_kv / tf_sendrecv_pivot / tf_comm_destroy; tokenflow_amd/sharded.py
+// describes the two exchange steps and is what the Python host uses).  The reference is single-process: new work.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1 on the first tf_comm_* call): libtokenflow_hip.so itself keeps no
+// link-time dependency on it, a single-GPU process never loads it, and inside a PyTorch process the loader hands back
+// the copy torch already mapped (same soname), so there is one RCCL per process.
+#include <dlfcn.h>
+#include <string.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+
+#include "tf_common.h"
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+// resolved once per process; read-only afterwards
+const Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) return;
+        auto sym = [&](const char* n) { return dlsym(r.handle, n); };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.Send && r.Recv && r.GroupStart &&
+               r.GroupEnd && r.GetErrorString;
+    });
+    return r;
+}
+
+int elem_bytes(int dtype) { return dtype == TF_F32 ? 4 : 2; }
+
+}  // namespace
+
+struct tf_comm {
+    ncclComm_t comm;
+    int rank, world;
+};
+
+#define TF_NEED_RCCL(what)                                                                          \
+    const Rccl& R = rccl();                                                                         \
+    if (!R.ok) {                                                                                    \
+        tf_set_error("%s: RCCL (librccl.so.1) could not be loaded or lacks a symbol", what);        \
+        return TF_ERR_COMM;                                                                         \
+    }
+#define TF_NCCL(call, what)                                                       \
+    do {                                                                          \
+        const ncclResult_t r_ = (call);                                           \
+        if (r_ != ncclSuccess) {                                                  \
+            tf_set_error("%s: %s", what, R.GetErrorString(r_));                   \
+            return TF_ERR_COMM;                                                   \
+        }                                                                         \
+    } while (0)
+
+extern "C" int tf_comm_unique_id(void* id_out) {
+    TF_ARG(id_out, TF_ERR_NULL, "tf_comm_unique_id: null pointer");
+    TF_NEED_RCCL("tf_comm_unique_id");
+    ncclUniqueId id;
+    TF_NCCL(R.GetUniqueId(&id), "tf_comm_unique_id");
+    memcpy(id_out, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return 0;
+}
+
+extern "C" int tf_comm_init(const void* unique_id, int rank, int world, tf_comm** comm_out) {
+    TF_ARG(unique_id && comm_out, TF_ERR_NULL, "tf_comm_init: null pointer");
+    TF_ARG(world > 0 && rank >= 0 && rank < world, TF_ERR_SHAPE, "tf_comm_init: rank %d of %d", rank, world);
+    TF_NEED_RCCL("tf_comm_init");
+    ncclUniqueId id;
+    memcpy(id.internal, unique_id, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t c;
+    TF_NCCL(R.CommInitRank(&c, world, id, rank), "tf_comm_init");   // binds the CURRENT device (hipSetDevice first)
+    *comm_out = new tf_comm{c, rank, world};
+    return 0;
+}
+
+extern "C" int tf_comm_destroy(tf_comm* comm) {
+    if (!comm) return 0;
+    TF_NEED_RCCL("tf_comm_destroy");
+    const ncclResult_t r = R.CommDestroy(comm->comm);
+    delete comm;
+    if (r != ncclSuccess) {
+        tf_set_error("tf_comm_destroy: %s", R.GetErrorString(r));
+        return TF_ERR_COMM;
+    }
+    return 0;
+}
+
+extern "C" int tf_comm_rank(const tf_comm* comm) { return comm ? comm->rank : -1; }
+extern "C" int tf_comm_world(const tf_comm* comm) { return comm ? comm->world : 0; }
+
+extern "C" int tf_allgather_kv(tf_comm* comm, const void* local, void* bank, int64_t elems_per_rank, int dtype,
+                               void* stream) {
+    TF_ARG(comm && local && bank, TF_ERR_NULL, "tf_allgather_kv: null pointer");
+    TF_ARG(dtype == TF_BF16 || dtype == TF_F16 || dtype == TF_F32, TF_ERR_DTYPE, "tf_allgather_kv: dtype %d", dtype);
+    TF_ARG(elems_per_rank > 0, TF_ERR_SHAPE, "tf_allgather_kv: elems_per_rank=%lld", (long long)elems_per_rank);
+    TF_NEED_RCCL("tf_allgather_kv");
+    // bytes, not typed elements: a gather moves data, and ncclBfloat16 needs no special casing this way
+    TF_NCCL(R.AllGather(local, bank, (size_t)elems_per_rank * elem_bytes(dtype), ncclUint8, comm->comm,
+                        reinterpret_cast<hipStream_t>(stream)),
+            "tf_allgather_kv");
+    return 0;
+}
+
+extern "C" int tf_all_to_all_rows(tf_comm* comm, const void* send, void* recv, const int64_t* send_rows,
+                                  const int64_t* recv_rows, int64_t row_elems, int dtype, void* stream) {
+    TF_ARG(comm && send && recv && send_rows && recv_rows, TF_ERR_NULL, "tf_all_to_all_rows: null pointer");
+    TF_ARG(dtype == TF_BF16 || dtype == TF_F16 || dtype == TF_F32, TF_ERR_DTYPE, "tf_all_to_all_rows: dtype %d", dtype);
+    TF_ARG(row_elems > 0, TF_ERR_SHAPE, "tf_all_to_all_rows: row_elems=%lld", (long long)row_elems);
+    TF_NEED_RCCL("tf_all_to_all_rows");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t rb = (size_t)row_elems * elem_bytes(dtype);
+    const char* s = static_cast<const char*>(send);
+    char* r = static_cast<char*>(recv);
+    for (int p = 0; p < comm->world; ++p)
+        TF_ARG(send_rows[p] >= 0 && recv_rows[p] >= 0, TF_ERR_SHAPE, "tf_all_to_all_rows: negative row count, peer %d", p);
+    TF_NCCL(R.GroupStart(), "tf_all_to_all_rows");
+    for (int p = 0; p < comm->world; ++p) {
+        if (send_rows[p]) TF_NCCL(R.Send(s, (size_t)send_rows[p] * rb, ncclUint8, p, comm->comm, st), "tf_all_to_all_rows");
+        if (recv_rows[p]) TF_NCCL(R.Recv(r, (size_t)recv_rows[p] * rb, ncclUint8, p, comm->comm, st), "tf_all_to_all_rows");
+        s += (size_t)send_rows[p] * rb;
+        r += (size_t)recv_rows[p] * rb;
+    }
+    TF_NCCL(R.GroupEnd(), "tf_all_to_all_rows");
+    return 0;
+}
+
+extern "C" int tf_sendrecv_pivot(tf_comm* comm, const void* const* send, const int64_t* send_elems, int n_send,
+                                 int send_peer, void* const* recv, const int64_t* recv_elems, int n_recv,
+                                 int recv_peer, int dtype, void* stream) {
+    TF_ARG(comm && (n_send == 0 || (send && send_elems)) && (n_recv == 0 || (recv && recv_elems)), TF_ERR_NULL,
+           "tf_sendrecv_pivot: null pointer");
+    TF_ARG(dtype == TF_BF16 || dtype == TF_F16 || dtype == TF_F32, TF_ERR_DTYPE, "tf_sendrecv_pivot: dtype %d", dtype);
+    TF_ARG(n_send >= 0 && n_recv >= 0 && send_peer < comm->world && recv_peer < comm->world, TF_ERR_SHAPE,
+           "tf_sendrecv_pivot: n_send=%d n_recv=%d peers=(%d,%d) world=%d", n_send, n_recv, send_peer, recv_peer,
+           comm->world);
+    TF_NEED_RCCL("tf_sendrecv_pivot");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t eb = elem_bytes(dtype);
+    TF_NCCL(R.GroupStart(), "tf_sendrecv_pivot");
+    if (send_peer >= 0)
+        for (int i = 0; i < n_send; ++i)
+            TF_NCCL(R.Send(send[i], (size_t)send_elems[i] * eb, ncclUint8, send_peer, comm->comm, st), "tf_sendrecv_pivot");
+    if (recv_peer >= 0)
+        for (int i = 0; i < n_recv; ++i)
+            TF_NCCL(R.Recv(recv[i], (size_t)recv_elems[i] * eb, ncclUint8, recv_peer, comm->comm, st), "tf_sendrecv_pivot");
+    TF_NCCL(R.GroupEnd(), "tf_sendrecv_pivot");
+    return 0;
+}
