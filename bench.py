@@ -61,9 +61,11 @@ def parse():
     ap.add_argument("--config", default="cfg2", choices=list(workload.CONFIGS))
     ap.add_argument("--pivotal-exchange", default="auto", choices=["auto", "heads", "bank"],
                     help="N > 1: how the pivotal pass is exchanged (sharded.py); auto = heads when they divide")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="N > 1: nccl (= RCCL); gloo lets several ranks share one GPU on a development box "
-                         "(functional check of the N > 1 path, its timing means nothing)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo", "hip"],
+                    help="N > 1: nccl (= RCCL through torch.distributed, the default); hip = the exchange steps through "
+                         "the library's C ABI (tf_comm_*: RCCL without torch.distributed on the data path; gloo carries "
+                         "only the barrier and the unique id); gloo lets several ranks share one GPU on a development "
+                         "box (functional check of the N > 1 path, its timing means nothing)")
     ap.add_argument("--per-chunk", action="store_true",
                     help="issue the propagation one call per chunk (the reference's granularity) instead of one "
                          "call per block over all chunks")
@@ -340,7 +342,7 @@ def parity_check(cfg, blocks, w):
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: become `torch.distributed.run` with N ranks on this node."""
     n_dev = torch.cuda.device_count()
-    if args.backend == "nccl" and n_dev < args.gpus:
+    if args.backend in ("nccl", "hip") and n_dev < args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible "
                  f"(use --backend gloo to let ranks share a GPU for a functional check)")
     with socket.socket() as s:
@@ -372,7 +374,13 @@ def main():
         else:
             dist.init_process_group("gloo")
     cfg = workload.CONFIGS[args.config]
-    shard = sharded.FrameShard(cfg.K)
+    hip_comm = None
+    if world > 1 and args.backend == "hip":
+        from tokenflow_amd.comm import HipComm
+        uid = [HipComm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)          # control plane only: the tensors never touch gloo
+        hip_comm = HipComm(uid[0], rank, world)
+    shard = sharded.FrameShard(cfg.K, comm=hip_comm)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     blocks = [Block(cfg, lvl, inj, shard, gen, dev) for lvl, inj in workload.BLOCKS]
     w = blend_w(cfg.chunk, dev)
@@ -382,7 +390,7 @@ def main():
     exch_name = (names[exchange] if exchange else names["heads"] if n_heads_ok == len(cfg.levels)
                  else names["bank"] if n_heads_ok == 0
                  else "frames<->heads all-to-all on the levels whose heads divide over the ranks, K/V bank all-gather on the others")
-    use_graph = args.graph and world == 1
+    use_graph = args.graph and world == 1   # capturing RCCL calls crashes in hipStreamEndCapture on this stack
 
     def barrier():
         if world > 1:
@@ -417,7 +425,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if hip_comm is not None else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if use_graph:                   # roofline bracket: separate eager pass (events cannot be read out of a graph)
@@ -483,7 +491,8 @@ def main():
                    else "one per block over all chunks (tf_nn_gather_blend_chunks)",
                    "launch": "HIP-graph replay" if use_graph else "eager",
                    "parallelism": "1 GPU" if world == 1 else
-                   "frames sharded over %d GPUs; pivotal pass: %s" % (world, exch_name),
+                   "frames sharded over %d GPUs; pivotal pass: %s%s" % (
+                       world, exch_name, "; exchanges through the C ABI (tf_comm_*)" if hip_comm is not None else ""),
                    "step_algorithmic_tflop": round((fa + fn) / 1e12, 2),
                    "step_tflops_achieved": round((fa + fn) / 1e12 / (ms_per_step * 1e-3), 1)},
         "roofline": plain if plain is not None else dual,
@@ -500,6 +509,8 @@ def main():
             lv = [int(x) for x in args.cpu_sample_levels.split(",") if x != ""]
             out["cpu_baseline"] = cpu_baseline(cfg, lv)
         print(json.dumps(out), flush=True)
+    if hip_comm is not None:
+        hip_comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -20,9 +20,17 @@ def _free_port():
 
 def _worker(rank, world, port, K, inject, mode, no_split, ret, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    hip_comm = None
     if backend == "nccl":        # RCCL: one GPU per rank
         torch.cuda.set_device(rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    elif backend == "hip":       # exchanges through the C ABI (tf_comm_*); gloo only hands the unique id around
+        torch.cuda.set_device(rank)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from tokenflow_amd.comm import HipComm
+        uid = [HipComm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        hip_comm = HipComm(uid[0], rank, world)
     else:                        # gloo: the ranks share cuda:0
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -47,7 +55,7 @@ def _worker(rank, world, port, K, inject, mode, no_split, ret, backend="gloo"):
         one.group, one.world, one.rank, one.K, one.Kl, one.kf0 = None, 1, 0, K, K, 0
         ref = [one.propagate(c, tgt[c], res[c], piv, inv, full, w, n) for c in range(K)]
         # sharded
-        sh = sharded.FrameShard(K)
+        sh = sharded.FrameShard(K, comm=hip_comm)
         Kl, f0 = sh.Kl, sh.kf0
         loc = lambda t: t.view(3, K, S, D)[:, f0:f0 + Kl].reshape(3 * Kl, S, D)
         out = sh.pivotal_attention(loc(q), loc(k), loc(v), h, d ** -0.5, inject, mode=mode)
@@ -97,14 +105,17 @@ def test_sharded_real_kernels_two_ranks(K, mode, inject, no_split):
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
-@pytest.mark.parametrize("K,mode,inject", [(4, "heads", False), (4, "heads", True), (5, "heads", True), (4, "bank", True)])
-def test_sharded_real_kernels_two_gpus_rccl(K, mode, inject):
+@pytest.mark.parametrize("backend", ["nccl", "hip"])
+@pytest.mark.parametrize("K,mode,inject", [(4, "heads", False), (4, "heads", True), (5, "heads", True), (4, "bank", True),
+                                           (5, "bank", False)])
+def test_sharded_real_kernels_two_gpus_rccl(K, mode, inject, backend):
     """The same comparison with one GPU per rank over RCCL (xGMI): the all-to-alls of the head re-sharding, the bank
-    all-gather and the grouped point-to-point halo on the real backend with a world of two."""
+    all-gather and the grouped point-to-point halo on the real backend with a world of two -- through
+    torch.distributed ("nccl") and through the library's own C-ABI exchange entry points ("hip")."""
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, K, inject, mode, True, ret, "nccl"), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, K, inject, mode, True, ret, backend), nprocs=2, join=True)
     assert dict(ret) == {0: True, 1: True}
 
 
@@ -222,3 +233,29 @@ def test_c_abi_comm_two_gpus(tmp_path):
     os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     mp.spawn(_comm_worker, args=(2, str(tmp_path / "uid"), ret), nprocs=2, join=True)
     assert ret[0] and ret[1]
+
+
+def test_frame_shard_over_c_abi_comm_single_rank():
+    """FrameShard on the C-ABI exchange entry points with a world of one (all the pool offers): the head re-sharding's
+    two all-to-alls run through RCCL on the side stream, ordered against the compute stream with events.
+    (Capturing these RCCL calls into a HIP graph was tried here and crashes inside hipStreamEndCapture with the RCCL
+    2.26.6 of this PyTorch build, so no per-rank graph over the collectives is offered.)"""
+    from tokenflow_amd import comm, ops, sharded
+    c = comm.HipComm(comm.HipComm.unique_id(), 0, 1)
+    old = ops.NO_SPLIT
+    ops.NO_SPLIT = True
+    try:
+        K, S, h, d = 3, 320, 2, 40
+        g = torch.Generator(device="cuda").manual_seed(5)
+        q, k, v = (torch.randn(3 * K, S, h * d, generator=g, device="cuda").bfloat16() for _ in range(3))
+        sh = sharded.FrameShard(K, comm=c)
+        assert sh.world == 1 and sh.Kl == K
+        for inject in (False, True):
+            full = ops.ext_attn(q, k, v, h, d ** -0.5, inject)
+            for _ in range(3):                                      # buffers are reused call after call
+                out = sh._pivotal_heads(q, k, v, h, d ** -0.5, inject)
+            torch.cuda.synchronize()
+            assert torch.equal(out, full)
+    finally:
+        ops.NO_SPLIT = old
+        c.close()

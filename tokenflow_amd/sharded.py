@@ -4,7 +4,9 @@ The reference is single-process (no parallelism of any kind); thi
 Rank r of W owns the contiguous chunks [r*C/W, (r+1)*C/W) of the video and the keyframes
 drawn from them (K = C keyframes, one per chunk, run_tokenflow_pnp.py:224).  Per block there
 are two exchange steps, both through torch.distributed (backend "nccl" = RCCL over xGMI on
-MI355X; "gloo" in the CPU tests):
+MI355X; "gloo" in the CPU tests) -- or, with `FrameShard(K, comm=HipComm(...))`, through the library's own C-ABI
+exchange entry points (tokenflow_amd/comm.py: RCCL without torch.distributed on the data path; the calls run on a
+side stream ordered against the compute stream with events):
 
  1. pivotal pass -- every query of a keyframe attends to the keys/values of ALL K keyframes
     of its branch (tokenflow_utils.py:133-138).  Two exchange patterns, same results:
@@ -50,6 +52,18 @@ class _Done:
         return True
 
 
+class _StreamWork:
+    """Completion handle of exchanges issued on the side stream: wait() orders the CURRENT stream behind them
+    (no host blocking -- the semantics of a c10d work object on the NCCL backend)."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def wait(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return True
+
+
 def _all_to_all(recv: torch.Tensor, send: torch.Tensor, group, out_rows=None, in_rows=None, async_op: bool = False):
     """dist.all_to_all_single over dim 0 (row counts per peer; None = equal).  gloo (development boxes, the
     single-GPU tests) moves host memory only, so device tensors are staged through the host there.  RCCL
@@ -66,10 +80,15 @@ class FrameShard:
     """K keyframes (= chunks) over the ranks of `group` in contiguous runs; the first K % W ranks hold one more
     (cfg5's 25 chunks over 8 ranks -> 4,3,3,3,3,3,3,3)."""
 
-    def __init__(self, K: int, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, K: int, group: Optional[dist.ProcessGroup] = None, comm=None):
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.comm = comm                       # tokenflow_amd.comm.HipComm: exchanges through the C ABI instead
+        self._cs = None                        # its side stream
+        if comm is not None:
+            self.world, self.rank = comm.world, comm.rank
+        else:
+            self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+            self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         if K < self.world:
             raise ValueError(f"{K} keyframes cannot be sharded over {self.world} ranks (a rank would own none)")
         self.K = K
@@ -93,6 +112,31 @@ class FrameShard:
             t = b[key] = torch.empty(shape, dtype=dtype, device=device)
         return t
 
+    def _side(self, tensors, fn):
+        """HipComm path: run `fn` (RCCL calls through the C ABI, asynchronous on the current stream) on the exchange
+        stream, ordered after everything already enqueued on the compute stream; returns the handle to wait on."""
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_cs", None) is None:
+            self._cs = torch.cuda.Stream()
+        self._cs.wait_stream(cur)
+        with torch.cuda.stream(self._cs):
+            fn()
+        if not torch.cuda.is_current_stream_capturing():
+            for t in tensors:
+                t.record_stream(self._cs)      # allocator: not reusable before the exchange stream is done with it
+        return _StreamWork(self._cs)
+
+    def _a2a(self, recv: torch.Tensor, send: torch.Tensor, out_rows=None, in_rows=None, async_op: bool = False):
+        """Row all-to-all over dim 0: out_rows[p] rows arrive from peer p, in_rows[p] rows go to peer p (None = equal)."""
+        comm = getattr(self, "comm", None)
+        if comm is None:
+            return _all_to_all(recv, send, self.group, out_rows, in_rows, async_op=async_op)
+        work = self._side([recv, send], lambda: comm.all_to_all_rows(send, recv, in_rows, out_rows))
+        if async_op:
+            return work
+        work.wait()
+        return None
+
     # ------------------------------------------------------------------ pivotal pass
     def gather_bank(self, k_local: torch.Tensor, v_local: torch.Tensor, inject: bool
                     ) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -113,13 +157,13 @@ class FrameShard:
                 if not need:
                     bank[b, sl].copy_(loc[b])               # only this rank's own frames are read
                 elif self.even:                             # straight into place, no re-layout
-                    works.append(dist.all_gather_into_tensor(bank[b], loc[b], group=self.group, async_op=True))
+                    works.append(self._allgather(bank[b], loc[b]))
                 else:                                       # uneven runs: equal-size padded contributions
                     Km = self.counts[0]
                     mine = torch.zeros(Km, S, D, dtype=loc.dtype, device=loc.device)
                     mine[:Kl].copy_(loc[b])
                     allp = torch.empty(W * Km, S, D, dtype=loc.dtype, device=loc.device)
-                    works.append(dist.all_gather_into_tensor(allp, mine, group=self.group, async_op=True))
+                    works.append(self._allgather(allp, mine))
                     pads.append((bank[b], allp.view(W, Km, S, D)))
         for w in works:
             w.wait()
@@ -127,6 +171,12 @@ class FrameShard:
             for r in range(W):
                 dst[self.offsets[r]:self.offsets[r] + self.counts[r]].copy_(allp[r, :self.counts[r]])
         return kb.view(3 * K, S, D), vb.view(3 * K, S, D)
+
+    def _allgather(self, bank: torch.Tensor, mine: torch.Tensor):
+        comm = getattr(self, "comm", None)
+        if comm is None:
+            return dist.all_gather_into_tensor(bank, mine, group=self.group, async_op=True)
+        return self._side([bank, mine], lambda: comm.allgather(mine, bank))
 
     def pivotal_attention(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool,
                           mode: Optional[str] = None):
@@ -170,8 +220,8 @@ class FrameShard:
         ns = len(slabs)
         send = ops.head_pack(slabs, W, out=self._buf("send", (W, Kl, ns, S, hd), dt, dev))
         recv = self._buf("recv", (K, ns, S, hd), dt, dev)
-        work = _all_to_all(recv.view(K, -1), send.view(W * Kl, -1), self.group,
-                           None if even else self.counts, None if even else [Kl] * W, async_op=True)
+        work = self._a2a(recv.view(K, -1), send.view(W * Kl, -1),
+                         None if even else self.counts, None if even else [Kl] * W, async_op=True)
         # ---- source branch: own-frame keys, all heads, stays local (overlaps the exchange)
         out = torch.empty(3, Kl, S, D, dtype=dt, device=dev)
         ops.ext_attn(q_local, k_local, v_local, heads, scale, inject, out=out.view(3 * Kl, S, D), part="source")
@@ -186,8 +236,8 @@ class FrameShard:
             ops.ext_attn_views(rp[0:2], rp[2:4], rp[4:6], o4, heads // W, scale, False, "bank", branch0=(1, 1, 1, 1))
         # ---- outputs back to the frame owners
         recv2 = self._buf("recv2", (W, Kl, 2, S, hd), dt, dev)        # [head group][my frames][uncond|cond]
-        _all_to_all(recv2.view(W * Kl, -1), send2.view(K, -1), self.group,
-                    None if even else [Kl] * W, None if even else self.counts)
+        self._a2a(recv2.view(W * Kl, -1), send2.view(K, -1),
+                  None if even else [Kl] * W, None if even else self.counts)
         ops.head_unpack(recv2, [out[1], out[2]])
         return out.view(3 * Kl, S, D)
 
@@ -242,6 +292,19 @@ class FrameShard:
 
     def _p2p(self, send_tensors, recv_tensors):
         """One grouped point-to-point exchange: `send_tensors` to rank r+1, `recv_tensors` from rank r-1."""
+        comm = getattr(self, "comm", None)
+        if comm is not None:
+            to = self.rank + 1 if self.rank + 1 < self.world else -1
+            frm = self.rank - 1 if self.rank > 0 else -1
+            if to < 0 and frm < 0:
+                return []
+            send_tensors = [t.contiguous() for t in send_tensors]
+
+            def go():       # one grouped call per element type (the C entry point takes one dtype per call)
+                for dt in dict.fromkeys(t.dtype for t in list(send_tensors) + list(recv_tensors)):
+                    comm.sendrecv([t for t in send_tensors if t.dtype == dt], to,
+                                  [t for t in recv_tensors if t.dtype == dt], frm)
+            return [self._side(list(send_tensors) + list(recv_tensors), go)]
         opsl = []
         if self.rank + 1 < self.world:
             peer = self._peer(self.rank + 1)
