@@ -30,7 +30,38 @@ def _data(K, n, S, h, d, seed=0):
     return q, k, v, piv, kf_out, tgt, res
 
 
-def _worker(rank, world, port, K, n, S, h, d, inject, mode, ret):
+class GlooComm:
+    """Stand-in for tokenflow_amd.comm.HipComm with the same interface and argument meaning, carried by gloo: lets
+    the CPU tests drive FrameShard's C-ABI-comm branch (argument order of the row all-to-all, the per-dtype grouping
+    of the halo messages, the padded all-gather of uneven runs) with a world of two."""
+
+    def __init__(self):
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def allgather(self, local, bank):
+        assert bank.numel() == self.world * local.numel() and local.is_contiguous() and bank.is_contiguous()
+        dist.all_gather_into_tensor(bank.view(-1), local.reshape(-1))
+        return bank
+
+    def all_to_all_rows(self, send, recv, send_rows=None, recv_rows=None):
+        assert send.is_contiguous() and recv.is_contiguous()
+        if send_rows is not None:
+            assert sum(send_rows) == send.shape[0] and sum(recv_rows) == recv.shape[0]
+        dist.all_to_all_single(recv, send, recv_rows, send_rows)
+        return recv
+
+    def sendrecv(self, send, send_peer, recv, recv_peer):
+        ts = list(send if send_peer >= 0 else []) + list(recv if recv_peer >= 0 else [])
+        if not ts:
+            return
+        assert len({t.dtype for t in ts}) == 1 and all(t.is_contiguous() for t in ts)   # one dtype per C call
+        opsl = [dist.P2POp(dist.isend, t, send_peer) for t in (send if send_peer >= 0 else [])]
+        opsl += [dist.P2POp(dist.irecv, t, recv_peer) for t in (recv if recv_peer >= 0 else [])]
+        for r in dist.batch_isend_irecv(opsl):
+            r.wait()
+
+
+def _worker(rank, world, port, K, n, S, h, d, inject, mode, ret, use_comm=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -51,7 +82,7 @@ def _worker(rank, world, port, K, n, S, h, d, inject, mode, ret):
             dt = torch.float32
             full_prop.append(fake.gather_blend(kf_out, idx, w if len(ids) == 2 else None, ids, n, res[c], dt))
         # ---- sharded
-        sh = sharded.FrameShard(K)
+        sh = sharded.FrameShard(K, comm=GlooComm() if use_comm else None)
         Kl, f0 = sh.Kl, sh.kf0
         loc = lambda t: t.view(3, K, S, D)[:, f0:f0 + Kl].reshape(3 * Kl, S, D)
         fake.calls.clear()
@@ -103,6 +134,18 @@ def test_uneven_shards(inject, mode):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, K, n, S, h, d, inject, mode, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+@pytest.mark.parametrize("K,mode,inject", [(4, "heads", True), (5, "heads", False), (4, "bank", False), (5, "bank", True)])
+def test_sharded_over_comm_interface(K, mode, inject):
+    """The same comparisons with FrameShard on its C-ABI-comm branch (`comm=`), a gloo-backed stand-in with HipComm's
+    interface doing the moving: even and uneven runs, both exchange patterns, halo in two halves."""
+    world, n, S, h, d = 2, 2, 12, 2, 8
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, K, n, S, h, d, inject, mode, ret, True), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
 
 

@@ -115,6 +115,9 @@ class FrameShard:
     def _side(self, tensors, fn):
         """HipComm path: run `fn` (RCCL calls through the C ABI, asynchronous on the current stream) on the exchange
         stream, ordered after everything already enqueued on the compute stream; returns the handle to wait on."""
+        if not tensors[0].is_cuda:             # host tensors (the CPU tests' stand-in comm): no streams to order
+            fn()
+            return _Done()
         cur = torch.cuda.current_stream()
         if getattr(self, "_cs", None) is None:
             self._cs = torch.cuda.Stream()
