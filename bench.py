@@ -29,6 +29,8 @@ Prints ONE JSON line (rank 0):
                 (profiles/traffic.json; collected separately, never in this run) or null.
   parity        in-run check against the oracle (after the timed region, rank 0, N = 1): max |out - ref| of the
                 level-0 attention on sampled rows, and the tie-aware NN index mismatch rate of a level-0 chunk.
+  roofline_other  NN search (MFMA roof) and gather/blend (HBM roof) on one level-0 chunk, HIP events, after the timed
+                region (rank 0, N = 1).
   yardstick     same box, same run, after the timed region (rank 0, N = 1): what the vendor libraries reach -- hipBLASLt
                 (torch.matmul, bf16 8192^3) and PyTorch-ROCm's fused attention (aotriton flash behind
                 scaled_dot_product_attention) on the level-0 bank problems.  Comparison points for the roofline
@@ -166,6 +168,52 @@ def usable_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def other_rooflines(cfg, blocks, w):
+    """The two other kernels of the path on a level-0 chunk (rank 0, N = 1, after the timed region; HIP events on
+    the launch stream): NN search against the MFMA roof, gather/blend against the HBM roof."""
+    blk = next(b for b in blocks if b.lvl == 0)
+    n, S, D, K = cfg.chunk, blk.S, blk.D, cfg.K
+    c = min(3, K - 1)
+    ids = [c, c - 1] if c > 0 else [c]
+    nS = n * S
+    tgt = blk.tgt[c * nS:(c + 1) * nS]
+    res = blk.res.view(3, K, n, S, D)[:, c].reshape(3 * n, S, D).contiguous()
+    kf_out = ops.ext_attn(blk.q, blk.k, blk.v, blk.h, (D // blk.h) ** -0.5, False)
+    inv = ops.pivot_inv_norm(blk.pivots)
+    idx = ops.nn_search(tgt, blk.pivots, inv, ids)
+
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    P = len(ids)
+    t_nn = timed(lambda: ops.nn_search(tgt, blk.pivots, inv, ids))
+    out_dt = torch.float32 if P == 2 else kf_out.dtype
+    t_gb = timed(lambda: ops.gather_blend(kf_out, idx, w if P == 2 else None, ids, n, res, out_dt))
+    fl = workload.nn_flops(n, S, D, P)
+    e_in, e_out = kf_out.element_size(), torch.empty(0, dtype=out_dt).element_size()
+    by = 3.0 * nS * D * (P * e_in + res.element_size() + e_out) + P * nS * 4
+    return [
+        {"kernel": "nn_search (level 0, ONE chunk against %d keyframes, search + finalize launches: GEMM + fused "
+                   "normalisation and argmax; the step itself searches all chunks of a block in one launch, "
+                   "profiles/r02_kernel_stats.csv)" % P,
+         "bound": "mfma", "achieved": round(fl / t_nn / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
+         "frac": round(fl / t_nn / 1e9 / 2500.0, 4), "avg_launch_ms": round(t_nn, 4),
+         "algorithmic_gflop_per_launch": round(fl / 1e9, 1)},
+        {"kernel": "gather_blend (level 0, one chunk: two gathered keyframe rows + residual -> fp32 result)",
+         "bound": "hbm", "achieved": round(by / t_gb / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+         "frac": round(by / t_gb / 1e6 / 8000.0, 4), "avg_launch_ms": round(t_gb, 4),
+         "algorithmic_mbytes_per_launch": round(by / 1e6, 1)},
+    ]
 
 
 def power_state(blocks):
@@ -502,6 +550,8 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_parity:
             out["parity"] = parity_check(cfg, blocks, w)
+        if world == 1 and not args.no_parity:
+            out["roofline_other"] = other_rooflines(cfg, blocks, w)
         if world == 1 and not args.no_yardstick:
             out["yardstick"] = yardstick(cfg)
             out["yardstick"]["power_state"] = power_state(blocks)
