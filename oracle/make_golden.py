@@ -25,7 +25,8 @@ Fixtures
                  checksum guards against RNG drift.
   inversion.pt   Preprocess.ddim_inversion / ddim_sample (preprocess.py:198-261), cut out of the reference's
                  syntax tree and executed unchanged on a stand-in model: the latents files written
-                 (names + contents), the inverted and the reconstructed latents.  fp32.
+                 (names + contents), the inverted and the reconstructed latents.  fp32, and float16 as the
+                 reference runs them (preprocess.py:195).
   adazero.pt     TokenFlowBlock.forward on an AdaLayerNormZero block (use_ada_layer_norm_zero:
                  gate_msa on the cached / selected attention outputs, 362-366; scale/shift/gate
                  on the feed-forward, 417-424): pivotal pass and chunks 0..K-1.
@@ -220,22 +221,28 @@ def load_reference_inversion():
 
 
 def gen_inversion():
-    """The verbatim inversion / reconstruction loops (preprocess.py:198-261) on the stand-in model, fp32 latents:
-    the files they write and the tensors they return."""
+    """The verbatim inversion / reconstruction loops (preprocess.py:198-261) on the stand-in model: the files they
+    write and the tensors they return.  fp32 latents, and (keys with the suffix `_f16`) the float16 latents the
+    reference actually inverts (preprocess.py:195 `.to(torch.float16)`), which pins the 16-bit rounding points of the
+    update to the reference itself."""
     import tempfile
     ref_inv, ref_sample = load_reference_inversion()
     model = gc.InversionModel()
-    latents, cond = gc.inversion_inputs()
-    out = dict(input_checksum=gc.checksum(latents, cond), files={})
-    with tempfile.TemporaryDirectory() as d:
-        os.makedirs(os.path.join(d, "latents"))
-        save_ts = model.scheduler.timesteps[::2]
-        inv = ref_inv(model, cond, latents.clone(), d, gc.INVERSION_CFG["batch_size"], save_latents=True,
-                      timesteps_to_save=save_ts)
-        for f in sorted(os.listdir(os.path.join(d, "latents"))):
-            out["files"][f] = digest(torch.load(os.path.join(d, "latents", f)), 3)
-        out["inverted"] = digest(inv, 1)
-        out["reconstructed"] = digest(ref_sample(model, inv.clone(), cond, gc.INVERSION_CFG["batch_size"]), 1)
+    out = {}
+    for dtype, sfx in ((torch.float32, ""), (torch.float16, "_f16")):
+        latents, cond = gc.inversion_inputs(dtype)
+        out["input_checksum" + sfx] = gc.checksum(latents, cond)
+        out["files" + sfx] = {}
+        with tempfile.TemporaryDirectory() as d:
+            os.makedirs(os.path.join(d, "latents"))
+            save_ts = model.scheduler.timesteps[::2]
+            inv = ref_inv(model, cond, latents.clone(), d, gc.INVERSION_CFG["batch_size"], save_latents=True,
+                          timesteps_to_save=save_ts)
+            assert inv.dtype == dtype
+            for f in sorted(os.listdir(os.path.join(d, "latents"))):
+                out["files" + sfx][f] = digest(torch.load(os.path.join(d, "latents", f)), 3)
+            out["inverted" + sfx] = digest(inv, 1)
+            out["reconstructed" + sfx] = digest(ref_sample(model, inv.clone(), cond, gc.INVERSION_CFG["batch_size"]), 1)
     return out
 
 

@@ -254,8 +254,11 @@ def ddim_step(x: torch.Tensor, eps: torch.Tensor, mu_a: float, sigma_a: float, m
     """`pred_x0 = (x - sigma_a*eps) / mu_a;  x' = mu_b*pred_x0 + sigma_b*eps` with the reference's operation
     order and per-op rounding: every torch op on a 16-bit tensor is evaluated in fp32 and rounded to the tensor
     dtype, the coefficients are fp32 scalars (on the reference's CUDA path `scheduler.alphas_cumprod` is a host
-    tensor, i.e. a scalar operand kept in fp32 opmath -- a CPU run of the same lines would round the scalars to the
-    tensor dtype first, which is why the fp16 golden of this step is generated in fp32 only)."""
+    tensor, i.e. a scalar operand kept in fp32 opmath.  A CPU run of the same lines rounds the three MULTIPLIED
+    0-dim coefficients to the tensor dtype first and keeps the divisor in fp32: the f16 golden of
+    tests/golden/inversion.pt, written by a CPU run of the verbatim reference, is reproduced bit for bit by this
+    function when it is handed those three coefficients pre-rounded -- tests/test_hooks_cpu.py -- which pins every
+    rounding point of the tensor arithmetic to the reference)."""
     dt = x.dtype
     r = (lambda t: t) if dt == torch.float32 else (lambda t: t.to(dt).float())
     xf, ef = x.float(), eps.float()

@@ -656,6 +656,29 @@ def test_ddim_step_bit_exact(dtype):
         assert torch.equal(dx.cpu(), ref)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_ddim_step_vs_torch_gpu_sequence(dtype):
+    """The same update as torch evaluates preprocess.py:224-225 ON THE GPU, coefficients as 0-dim CPU tensors the way
+    `scheduler.alphas_cumprod[t] ** 0.5` arrives there.  torch's GPU true-divide by a host scalar multiplies by an
+    fp32 reciprocal, the kernel divides (IEEE, = torch on the CPU, which the golden fixture pins): pred_x0 may differ
+    by one rounding of the tensor dtype, which the last two ops carry through -- bound: 2 ulp of the dtype at the
+    result's magnitude, on a small fraction of the elements; fp32 within 4 fp32 ulp."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    x, eps = (torch.randn(40, 4, 64, 64, generator=g).to(dtype).cuda() for _ in range(2))
+    a_prev, a_t = torch.tensor(0.9475), torch.tensor(0.9180)          # alphas_cumprod entries (CPU, fp32)
+    mu_a, sg_a, mu_b, sg_b = a_prev ** 0.5, (1 - a_prev) ** 0.5, a_t ** 0.5, (1 - a_t) ** 0.5
+    pred_x0 = (x - sg_a * eps) / mu_a                                   # the reference's lines, on the GPU
+    ref = mu_b * pred_x0 + sg_b * eps
+    out = ops.ddim_step(x, eps, float(mu_a), float(sg_a), float(mu_b), float(sg_b))
+    assert out.dtype == ref.dtype == dtype
+    ulp = {torch.float32: 2.0 ** -23, torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7}[dtype]
+    err = (out.float() - ref.float()).abs()
+    tol = (4 if dtype == torch.float32 else 2) * ulp * ref.float().abs().clamp_min(2.0 ** -6)
+    assert bool((err <= tol).all()), float((err / tol).max())
+    assert float((err > 0).float().mean()) < 0.25
+
+
 def test_ddim_inversion_on_gpu_against_reference_golden(tmp_path):
     """The inversion + reconstruction loops of `tokenflow_amd.inversion` on the GPU (HIP update kernel, stand-in
     UNet evaluated by torch on the GPU) against the verbatim reference's CPU run: 2e-5 (the stand-in's tanh differs

@@ -315,30 +315,47 @@ def test_library_exports_every_declared_symbol():
     assert lib.tf_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define TF_ABI_VERSION (\d+)", hdr).group(1))
 
 
-def test_ddim_inversion_matches_reference_golden(tmp_path, monkeypatch):
+@pytest.mark.parametrize("dtype,sfx", [(torch.float32, ""), (torch.float16, "_f16")])
+def test_ddim_inversion_matches_reference_golden(tmp_path, monkeypatch, dtype, sfx):
     """Row f4: `tokenflow_amd.inversion.ddim_inversion` / `ddim_sample` (latent update through the oracle-backed
     `ddim_step`) against what the VERBATIM `Preprocess.ddim_inversion` / `ddim_sample` (preprocess.py:198-261,
-    executed unchanged by oracle/make_golden.py) wrote and returned: same file names, same contents bit for bit in
-    fp32 (same operation order, no fused multiply-add), same in-place update of the caller's tensor."""
+    executed unchanged by oracle/make_golden.py) wrote and returned: same file names, same contents bit for bit
+    (same operation order, same rounding points, no fused multiply-add), same in-place update of the caller's
+    tensor -- in fp32 and in the float16 the reference inverts in (preprocess.py:195)."""
     import os
     from tests.conftest import load_golden
     from tokenflow_amd import inversion
-    monkeypatch.setattr(inversion, "ops", FakeOps())
+
+    class CpuScalarOps(FakeOps):
+        """torch on the CPU casts a 0-dim FIRST operand (`sigma_prev * eps`, `mu * pred_x0`, `sigma * eps`: 0-dim fp32
+        tensors) to the tensor dtype before a 16-bit multiply, while a 0-dim divisor (`/ mu_prev`) stays in fp32
+        opmath; on a GPU every host scalar stays in fp32 opmath -- the form `tf_ddim_step` and the oracle
+        implement.  The golden was written by a CPU run of the reference, so its f16 case is reproduced by the same
+        update with the three MULTIPLIED coefficients rounded to f16 first: every rounding point of the tensor
+        arithmetic (product, difference, quotient, product, product, sum) is the reference's own."""
+
+        def ddim_step(self, x, eps, mu_a, sigma_a, mu_b, sigma_b, out=None):
+            rnd = lambda c: float(torch.tensor(c, dtype=torch.float32).to(x.dtype))
+            return super().ddim_step(x, eps, mu_a, rnd(sigma_a), rnd(mu_b), rnd(sigma_b), out=out)
+
+    monkeypatch.setattr(inversion, "ops", CpuScalarOps())
     g = load_golden("inversion.pt")
     model = gc.InversionModel()
-    latents, cond = gc.inversion_inputs()
-    assert gc.checksum(latents, cond) == g["input_checksum"], "RNG drift"
+    latents, cond = gc.inversion_inputs(dtype)
+    assert gc.checksum(latents, cond) == g["input_checksum" + sfx], "RNG drift"
     os.makedirs(tmp_path / "latents")
     work = latents.clone()
     inv = inversion.ddim_inversion(model, cond, work, str(tmp_path), gc.INVERSION_CFG["batch_size"], save_latents=True,
                                    timesteps_to_save=model.scheduler.timesteps[::2])
-    assert inv is work                                                   # updated in place, as the reference
-    assert sorted(os.listdir(tmp_path / "latents")) == sorted(g["files"])
-    for name, dg in g["files"].items():
-        check(torch.load(tmp_path / "latents" / name), dg, 0.0, name)
+    assert inv is work and inv.dtype == dtype                            # updated in place, as the reference
+    assert sorted(os.listdir(tmp_path / "latents")) == sorted(g["files" + sfx])
+    for name, dg in g["files" + sfx].items():
+        saved = torch.load(tmp_path / "latents" / name)
+        assert str(saved.dtype) == dg["dtype"]
+        check(saved, dg, 0.0, name)
         assert tfu.load_source_latents_t(int(name.split("_")[-1][:-3]), str(tmp_path / "latents")).shape == dg["shape"]
-    check(inv, g["inverted"], 0.0, "inverted")
-    check(inversion.ddim_sample(model, inv.clone(), cond, gc.INVERSION_CFG["batch_size"]), g["reconstructed"], 0.0,
+    check(inv, g["inverted" + sfx], 0.0, "inverted")
+    check(inversion.ddim_sample(model, inv.clone(), cond, gc.INVERSION_CFG["batch_size"]), g["reconstructed" + sfx], 0.0,
           "reconstructed")
     assert inversion.latents_save_path("latents", "2.1", "data/wolf.mp4", 500, 40) == \
         os.path.join("latents", "sd_2.1", "wolf", "steps_500", "nframes_40")       # preprocess.py:305-309

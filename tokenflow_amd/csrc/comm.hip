@@ -79,6 +79,24 @@ struct tf_comm {
         }                                                                         \
     } while (0)
 
+// Inside ncclGroupStart/End: remember the FIRST failure and keep going to the GroupEnd -- returning early would leave
+// the thread's RCCL group open, and every later collective of the process (torch.distributed's included: one RCCL per
+// process) would be queued into a group that never closes.
+#define TF_NCCL_IN_GROUP(call, first_err)                        \
+    do {                                                         \
+        const ncclResult_t r_ = (call);                          \
+        if (r_ != ncclSuccess && (first_err) == ncclSuccess) (first_err) = r_; \
+    } while (0)
+#define TF_NCCL_GROUP_END(first_err, what)                                        \
+    do {                                                                          \
+        const ncclResult_t e_ = R.GroupEnd();                                     \
+        const ncclResult_t r_ = (first_err) != ncclSuccess ? (first_err) : e_;    \
+        if (r_ != ncclSuccess) {                                                  \
+            tf_set_error("%s: %s", what, R.GetErrorString(r_));                   \
+            return TF_ERR_COMM;                                                   \
+        }                                                                         \
+    } while (0)
+
 extern "C" int tf_comm_unique_id(void* id_out) {
     TF_ARG(id_out, TF_ERR_NULL, "tf_comm_unique_id: null pointer");
     TF_NEED_RCCL("tf_comm_unique_id");
@@ -141,13 +159,14 @@ extern "C" int tf_all_to_all_rows(tf_comm* comm, const void* send, void* recv, c
     for (int p = 0; p < comm->world; ++p)
         TF_ARG(send_rows[p] >= 0 && recv_rows[p] >= 0, TF_ERR_SHAPE, "tf_all_to_all_rows: negative row count, peer %d", p);
     TF_NCCL(R.GroupStart(), "tf_all_to_all_rows");
+    ncclResult_t first = ncclSuccess;
     for (int p = 0; p < comm->world; ++p) {
-        if (send_rows[p]) TF_NCCL(R.Send(s, (size_t)send_rows[p] * rb, ncclUint8, p, comm->comm, st), "tf_all_to_all_rows");
-        if (recv_rows[p]) TF_NCCL(R.Recv(r, (size_t)recv_rows[p] * rb, ncclUint8, p, comm->comm, st), "tf_all_to_all_rows");
+        if (send_rows[p]) TF_NCCL_IN_GROUP(R.Send(s, (size_t)send_rows[p] * rb, ncclUint8, p, comm->comm, st), first);
+        if (recv_rows[p]) TF_NCCL_IN_GROUP(R.Recv(r, (size_t)recv_rows[p] * rb, ncclUint8, p, comm->comm, st), first);
         s += (size_t)send_rows[p] * rb;
         r += (size_t)recv_rows[p] * rb;
     }
-    TF_NCCL(R.GroupEnd(), "tf_all_to_all_rows");
+    TF_NCCL_GROUP_END(first, "tf_all_to_all_rows");
     return 0;
 }
 
@@ -164,12 +183,13 @@ extern "C" int tf_sendrecv_pivot(tf_comm* comm, const void* const* send, const i
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t eb = elem_bytes(dtype);
     TF_NCCL(R.GroupStart(), "tf_sendrecv_pivot");
+    ncclResult_t first = ncclSuccess;
     if (send_peer >= 0)
         for (int i = 0; i < n_send; ++i)
-            TF_NCCL(R.Send(send[i], (size_t)send_elems[i] * eb, ncclUint8, send_peer, comm->comm, st), "tf_sendrecv_pivot");
+            TF_NCCL_IN_GROUP(R.Send(send[i], (size_t)send_elems[i] * eb, ncclUint8, send_peer, comm->comm, st), first);
     if (recv_peer >= 0)
         for (int i = 0; i < n_recv; ++i)
-            TF_NCCL(R.Recv(recv[i], (size_t)recv_elems[i] * eb, ncclUint8, recv_peer, comm->comm, st), "tf_sendrecv_pivot");
-    TF_NCCL(R.GroupEnd(), "tf_sendrecv_pivot");
+            TF_NCCL_IN_GROUP(R.Recv(recv[i], (size_t)recv_elems[i] * eb, ncclUint8, recv_peer, comm->comm, st), first);
+    TF_NCCL_GROUP_END(first, "tf_sendrecv_pivot");
     return 0;
 }

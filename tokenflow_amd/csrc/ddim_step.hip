@@ -7,7 +7,11 @@
 // Arithmetic follows the reference op by op: every intermediate is rounded to the tensor dtype (torch evaluates a
 // 16-bit op in fp32 and rounds its result; the four coefficients are fp32 scalars, as they are on the reference's
 // CUDA path where scheduler.alphas_cumprod lives on the host), no fused multiply-add, IEEE division -- so the
-// result is bit-identical to the reference's sequence in fp32, f16 and bf16.
+// result is bit-identical to the reference's sequence AS TORCH EVALUATES IT ON THE CPU (what the golden fixture
+// tests/golden/inversion.pt pins) in fp32, f16 and bf16.  On a GPU torch's true-divide by a host scalar takes a
+// fast path, x * (1 / mu) with the reciprocal formed once in fp32, so there pred_x0 can differ from this kernel's
+// IEEE quotient by one rounding of the tensor dtype on a small fraction of the elements
+// (tests/test_kernels_gpu.py::test_ddim_step_vs_torch_gpu_sequence bounds it).
 #include "tf_common.h"
 
 #pragma clang fp contract(off)
@@ -21,8 +25,8 @@ __device__ __forceinline__ float rnd(float x) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void ddim_step_kernel(const T* __restrict__ x, const T* __restrict__ eps,
-                                                        T* __restrict__ out, int64_t n, float mu_a, float sigma_a,
+__global__ __launch_bounds__(256) void ddim_step_kernel(const T* x, const T* __restrict__ eps,   // out may alias x:
+                                                        T* out, int64_t n, float mu_a, float sigma_a,   // no restrict
                                                         float mu_b, float sigma_b) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float xe = (float)x[i], e = (float)eps[i];

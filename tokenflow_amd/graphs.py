@@ -57,6 +57,7 @@ class GraphCache:
         self._pool = None
         self._share_pool = share_pool
         self._warmup = warmup
+        self._side = None          # ONE warm-up stream per cache (ops._workspace caches scratch per stream)
 
     def __len__(self):
         return len(self._entries)
@@ -85,13 +86,17 @@ class GraphCache:
             raise TypeError("GraphCache: inputs must be CUDA tensors (everything else belongs in the key)")
         static_in = tuple(t.clone() for t in inputs)
         # eager warm-up on a side stream (lazy initialisation, autotuning, workspace growth must not be captured)
-        side = torch.cuda.Stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        side = self._side
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(self._warmup):
                 fn(*static_in)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        from . import ops
+        ops.drop_workspaces(side)      # the warm-up's scratch (tens of MB at level 0) is not needed again
         graph = torch.cuda.CUDAGraph()
         pool = None
         if self._share_pool:

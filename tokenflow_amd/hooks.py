@@ -220,8 +220,10 @@ def _fused_qkv(attn, x: torch.Tensor):
     section 8; tokenflow_utils.py:120-122 issues three Linear calls): one GEMM, one output [3K, S, 3D] that the
     attention kernel reads in place through its row stride, no per-tensor dtype casts.  The concatenated weight is
     cached on the module, keyed by the three weights' storage, version counter and the compute dtype, so an
-    optimizer step, a `.to()` or a LoRA merge rebuilds it.  Returns None when the three projections are not
-    plain bias-compatible `nn.Linear` layers over the same input (then the caller issues them one by one).
+    optimizer step, a `.to()` or an in-place LoRA merge rebuilds it.  (An edit THROUGH `.data` -- `w.data.add_(d)` --
+    bumps no version counter: call `invalidate_fused_qkv(model)` after one.)  Returns None when the three
+    projections are not plain bias-compatible `nn.Linear` layers over the same input, or when autograd is recording
+    and a weight requires grad (then the caller issues them one by one).
     Returns the [..., 3D] projection output; q, k, v are its three D-wide column slabs."""
     lq, lk, lv = attn.to_q, attn.to_k, attn.to_v
     Linear = torch.nn.Linear
@@ -233,6 +235,8 @@ def _fused_qkv(attn, x: torch.Tensor):
     biases = (lq.bias, lk.bias, lv.bias)
     if any(b is None for b in biases) != all(b is None for b in biases):
         return None
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (wq, wk, wv) + biases):
+        return None      # the cached concatenation is built without autograd: training keeps the three Linear calls
     if torch.is_autocast_enabled("cuda"):
         cdt = torch.get_autocast_dtype("cuda")
     else:
@@ -255,6 +259,12 @@ def _fused_qkv(attn, x: torch.Tensor):
 
 
 FUSE_QKV = os.environ.get("TOKENFLOW_FUSED_QKV", "1") not in ("", "0")
+
+
+def invalidate_fused_qkv(model: torch.nn.Module) -> None:
+    """Drop every cached [Wq;Wk;Wv] of `model` (needed only after weight edits that bypass the version counters)."""
+    for m in model.modules():
+        m.__dict__.pop("_tf_qkv_cache", None)
 
 
 def _make_sa_forward(self, pnp: bool):
@@ -398,6 +408,19 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
 
     class TokenFlowBlock(block_class):
 
+        @property
+        def pivot_hidden_states(self):
+            """`norm1` output of the last pivotal pass (tokenflow_utils.py:327), in the dtype the reference caches."""
+            st = self.__dict__.get("_tf_pivot_hidden")
+            if st is None:
+                raise AttributeError("pivot_hidden_states: no pivotal pass has run")
+            t, dt = st
+            return t if t.dtype == dt else t.to(dt)
+
+        @pivot_hidden_states.setter
+        def pivot_hidden_states(self, value):
+            self.__dict__["_tf_pivot_hidden"] = (value, value.dtype)
+
         def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None,
                     encoder_attention_mask=None, timestep=None, cross_attention_kwargs=None,
                     class_labels=None) -> torch.Tensor:
@@ -420,7 +443,13 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
             cross_attention_kwargs = cross_attention_kwargs if cross_attention_kwargs is not None else {}
             if self.pivotal_pass:
                 # 326-327 + 352-360: cache the normalised features and the attention output
-                self.pivot_hidden_states = norm_hidden_states
+                # the reference caches what norm1 returns (327): fp32 under autocast, where torch evaluates
+                # layer_norm in fp32.  The fused norm emitted 16-bit rows; the attribute keeps the reference's
+                # dtype and is widened only if somebody reads it (nothing on the path does: the NN search reads
+                # _tf_pivots / _tf_pivot_inv_norm)
+                self._tf_pivot_hidden = (norm_hidden_states,
+                                         torch.float32 if (norm_inv is not None and torch.is_autocast_enabled("cuda"))
+                                         else norm_hidden_states.dtype)
                 src = norm_hidden_states[0]
                 self._tf_pivots = src.to(ops.compute_dtype(src)).contiguous()       # [K,S,D] 16-bit
                 self._tf_pivot_inv_norm = (norm_inv.view(3, n_frames, sequence_length)[0] if norm_inv is not None

@@ -52,7 +52,12 @@ _attn_ws_bytes = {}   # (K, S, H, Dh, dtype) -> scratch bytes of tf_ext_attn_fwd
 def _workspace(nbytes: int, device, tag: str = "attn") -> torch.Tensor:
     """Scratch for one launch, cached per (purpose, device, stream).  While a HIP graph is being captured the
     buffer comes from the graph's private pool and must live and die with that graph: never cached."""
-    if torch.cuda.is_current_stream_capturing():
+    if device.index != torch.cuda.current_device():      # capture state is a property of the TENSORS' device's stream
+        with torch.cuda.device(device):
+            capturing = torch.cuda.is_current_stream_capturing()
+    else:
+        capturing = torch.cuda.is_current_stream_capturing()
+    if capturing:
         return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
     key = (tag, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _ws_cache.get(key)
@@ -60,6 +65,16 @@ def _workspace(nbytes: int, device, tag: str = "attn") -> torch.Tensor:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     return ws
+
+
+def drop_workspaces(stream=None) -> None:
+    """Forget the cached scratch of `stream` (a torch.cuda.Stream; None = every stream): the memory goes back to
+    torch's allocator once the launches that used it have run."""
+    if stream is None:
+        _ws_cache.clear()
+        return
+    for key in [k for k in _ws_cache if k[2] == stream.cuda_stream]:
+        del _ws_cache[key]
 
 
 # TOKENFLOW_FOLD_SCALE=1: at head dim 40 fold the softmax scale into q (rounded to the input dtype): several % faster,
