@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TF_ABI_VERSION 2
+#define TF_ABI_VERSION 3
 
 /* element types */
 #define TF_BF16 0
@@ -110,8 +110,10 @@ int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void* out,
 /* The same with explicit branch / frame strides (elements), for callers whose q, k, v arrive in the layout a
  * collective delivers them and whose output feeds the next collective (tokenflow_amd/sharded.py: the received
  * all-to-all buffer is [frame][slab][S][H*Dh], the returned one [frame][branch][S][H*Dh]):
- *   strides = { q_branch, q_frame, k_branch, k_frame, v_branch, v_frame, out_branch, out_frame }
- *   element (b, f, s, c) of q is q[b*q_branch + f*q_frame + s*ld + c]; out has token stride H*Dh.
+ *   strides = { q_branch, q_frame, k_branch, k_frame, v_branch, v_frame, out_branch, out_frame, q_token }   (9 values)
+ *   element (b, f, s, c) of k / v is k[b*k_branch + f*k_frame + s*ld + c], of q  q[b*q_branch + f*q_frame + s*q_token + c]
+ *   (q has its own token stride since ABI 3: a rank's queries may be a column slab of its fused projection output
+ *   while the bank arrives from an all-gather as dense slabs); out has token stride H*Dh.
  * Branch b of a tensor is addressed as base + b*branch_stride even when a call never touches branch 0 (bank-only
  * calls): pass base = (first touched slab) - b*branch_stride.  tf_ext_attn_fwd is this function with dense strides. */
 int tf_ext_attn_fwd_strided(const void* q, const void* k, const void* v, void* out,
@@ -271,6 +273,8 @@ int tf_inject_copy(void* x, int64_t elems_per_branch, int elem_bytes, void* stre
  * these).  Frames are sharded over the ranks:
  *   pivotal pass  (tokenflow_utils.py:133-138: every keyframe's queries read the keys/values of ALL K keyframes)
  *       tf_allgather_kv      each rank contributes its keyframes' slab, all ranks receive the bank (equal slabs), or
+ *       tf_allgather_rows    the same for runs of different lengths (K % W != 0): rank p contributes rows[p] rows of
+ *                            row_elems elements, every rank receives all of them in rank order, straight into place, or
  *       tf_all_to_all_rows   frames <-> heads re-sharding: rows [send_rows[p]] to peer p, [recv_rows[p]] from peer p
  *                            (row = row_elems elements; send / recv buffers are the concatenation in peer order);
  *   propagation   (331-333: chunk c reads keyframes c and c-1)
@@ -291,6 +295,8 @@ int tf_comm_destroy(tf_comm* comm);
 int tf_comm_rank(const tf_comm* comm);
 int tf_comm_world(const tf_comm* comm);
 int tf_allgather_kv(tf_comm* comm, const void* local, void* bank, int64_t elems_per_rank, int dtype, void* stream);
+int tf_allgather_rows(tf_comm* comm, const void* local, void* bank, const int64_t* rows, int64_t row_elems, int dtype,
+                      void* stream);
 int tf_all_to_all_rows(tf_comm* comm, const void* send, void* recv, const int64_t* send_rows, const int64_t* recv_rows,
                        int64_t row_elems, int dtype, void* stream);
 int tf_sendrecv_pivot(tf_comm* comm, const void* const* send, const int64_t* send_elems, int n_send, int send_peer,

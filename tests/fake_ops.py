@@ -24,7 +24,7 @@ class FakeOps:
         return t.dtype
 
     def ext_attn(self, q, k, v, heads, scale, inject, out=None, q_frame0=0, fold_scale=None, part="all",
-                 out_dtype=None):
+                 out_dtype=None, no_split=None):
         self.calls.append(("ext_attn", tuple(q.shape), bool(inject)) + ((part,) if part != "all" else ()))
         K, Kq = k.shape[0] // 3, q.shape[0] // 3
         qf, kf, vf = self._r(q).clone(), self._r(k).clone(), self._r(v).clone()
@@ -56,7 +56,7 @@ class FakeOps:
         return out
 
     def ext_attn_views(self, q, k, v, out, heads, scale, inject, part="all", branch0=(0, 0, 0, 0), q_frame0=0,
-                       fold_scale=None):
+                       fold_scale=None, no_split=None):
         """Strided 4-D views [branches b0.., frames, S, D]: materialise dense [3F,S,D] tensors (branches a call
         may not read stay NaN), run `ext_attn`, scatter the computed branches into the `out` view."""
         K, Kq, S, D = k.shape[1], q.shape[1], k.shape[2], k.shape[3]

@@ -1,7 +1,9 @@
-"""Frame-sharded path on 2 CPU processes (gloo): the exchange logic of
+"""Frame-sharded path on 2 and on 8 CPU processes (gloo): the exchange logic of
 tokenflow_amd/sharded.py with the oracle-backed FakeOps standing in for the HIP ops.
 Sharded results must equal the single-process results bit for bit (work is partitioned,
-not re-associated)."""
+not re-associated).  World 8 runs BASELINE configs 3 and 5 at their own rank geometry
+(toy token counts): K = 8 -> one keyframe and one chunk per rank, K = 25 -> runs of
+4,3,3,3,3,3,3,3 with head counts that do not divide over the ranks."""
 import os
 import socket
 
@@ -41,6 +43,20 @@ class GlooComm:
     def allgather(self, local, bank):
         assert bank.numel() == self.world * local.numel() and local.is_contiguous() and bank.is_contiguous()
         dist.all_gather_into_tensor(bank.view(-1), local.reshape(-1))
+        return bank
+
+    def allgather_rows(self, local, bank, rows):
+        assert local.is_contiguous() and bank.is_contiguous() and sum(rows) == bank.shape[0]
+        assert local.shape[0] == rows[self.rank] and len(rows) == self.world
+        parts = list(bank.split(list(rows)))
+        opsl = []
+        for p in range(self.world):
+            if p == self.rank:
+                parts[p].copy_(local)
+            else:
+                opsl += [dist.P2POp(dist.isend, local, p), dist.P2POp(dist.irecv, parts[p], p)]
+        for r in dist.batch_isend_irecv(opsl):
+            r.wait()
         return bank
 
     def all_to_all_rows(self, send, recv, send_rows=None, recv_rows=None):
@@ -89,7 +105,7 @@ def _worker(rank, world, port, K, n, S, h, d, inject, mode, ret, use_comm=False)
         out = sh.pivotal_attention(loc(q), loc(k), loc(v), h, d ** -0.5, inject, mode=mode)
         ok = torch.equal(out, loc(full_attn))
         parts = [c[3] if len(c) > 3 else "all" for c in fake.calls if c[0] == "ext_attn"]
-        want = ["source", "bank"] if (mode or ("heads" if h % world == 0 else "bank")) == "heads" else ["all"]
+        want = ["source", "bank"] if (mode or sh.auto_mode(h, S)) == "heads" else ["all"]
         ok = ok and parts == want
         piv_e, inv_e, kfo_e = sh.exchange_halo(piv[f0:f0 + Kl], inv[f0:f0 + Kl], loc(kf_out))
         for j in range(Kl):
@@ -147,6 +163,33 @@ def test_sharded_over_comm_interface(K, mode, inject):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, K, n, S, h, d, inject, mode, ret, True), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+@pytest.mark.parametrize("inject", [False, True])
+@pytest.mark.parametrize("K,h,mode", [(8, 8, "heads"), (8, 8, None), (8, 8, "bank"), (25, 5, None), (25, 10, None)])
+def test_world8_baseline_geometries(K, h, mode, inject):
+    """BASELINE config 3 (K = 8 keyframes over 8 ranks: Kl = 1, the rank's ONLY chunk sits behind the halo, so
+    `propagate_all(..., halo_reqs)` runs with no local chunk to issue first; 8 heads -> head re-sharding, also the
+    per-block default and the single-collective bank form) and config 5 (K = 25: runs 4,3,3,3,3,3,3,3; SD2.1's 5 / 10
+    heads do not divide over 8 ranks -> bank form through the row all-gather), both injection states: every rank
+    equal to the single-process result bit for bit."""
+    world, n, S, d = 8, 2, 6, 4
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, K, n, S, h, d, inject, mode, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_world8_over_comm_interface():
+    """Config 5's uneven runs at world 8 on FrameShard's C-ABI-comm branch (`allgather_rows`, uneven `all_to_all_rows`,
+    per-dtype halo groups)."""
+    world, K, n, S, h, d = 8, 25, 2, 6, 5, 4
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, K, n, S, h, d, False, None, ret, True), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
 
 
 def test_shard_runs():

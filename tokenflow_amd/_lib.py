@@ -10,7 +10,7 @@ TF_BF16, TF_F16, TF_F32 = 0, 1, 2
 TF_ATTN_INJECT, TF_ATTN_EXACT_SCALE, TF_ATTN_BANK_ONLY, TF_ATTN_SOURCE_ONLY, TF_ATTN_NO_SPLIT = 1, 2, 4, 8, 16
 TF_ATTN_OUT_F32 = 32
 TF_ATTN_FOLD_SCALE = 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 TF_ERR_COMM = -6
 
 _c = ctypes
@@ -47,6 +47,7 @@ _SIGNATURES = {
     "tf_comm_rank": (_c.c_int, [_c.c_void_p]),
     "tf_comm_world": (_c.c_int, [_c.c_void_p]),
     "tf_allgather_kv": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p]),
+    "tf_allgather_rows": (_c.c_int, [_c.c_void_p] * 4 + [_c.c_int64, _c.c_int, _c.c_void_p]),
     "tf_all_to_all_rows": (_c.c_int, [_c.c_void_p] * 5 + [_c.c_int64, _c.c_int, _c.c_void_p]),
     "tf_sendrecv_pivot": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p,
                                      _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),

@@ -8,6 +8,7 @@ One process per GPU:
     uid = HipComm.unique_id() on rank 0, handed to the other ranks by the host (file, socket, ...)
     comm = HipComm(uid, rank, world)              # binds the current device
     comm.allgather(local, bank)                   # K/V bank of the pivotal pass (tokenflow_utils.py:133-138)
+    comm.allgather_rows(local, bank, rows)        # the same for runs of different lengths
     comm.all_to_all_rows(send, recv, send_rows, recv_rows)      # frames <-> heads re-sharding
     comm.sendrecv([piv_last, inv_last, ...], rank + 1, [piv_halo, inv_halo, ...], rank - 1)   # 331-333
 
@@ -72,6 +73,20 @@ class HipComm:
             raise ValueError(f"bank has {bank.numel()} elements, expected {self.world} x {local.numel()}")
         _lib.check(_lib.load().tf_allgather_kv(self._h, local.data_ptr(), bank.data_ptr(), local.numel(), dt,
                                                _stream(local)), "tf_allgather_kv")
+        return bank
+
+    def allgather_rows(self, local: torch.Tensor, bank: torch.Tensor, rows: Sequence[int]):
+        """bank [sum(rows), ...] <- rank p's `local` [rows[p], ...] for every p, in rank order (runs of different
+        lengths: K keyframes over W ranks with K % W != 0)."""
+        dt = _dev(local, bank)
+        rows = list(rows)
+        row = bank[0].numel()
+        if len(rows) != self.world or sum(rows) != bank.shape[0] or local.shape[0] != rows[self.rank] or \
+                (local.shape[0] and local[0].numel() != row):
+            raise ValueError("allgather_rows: row counts do not match the buffers")
+        rr = (ctypes.c_int64 * self.world)(*rows)
+        _lib.check(_lib.load().tf_allgather_rows(self._h, local.data_ptr(), bank.data_ptr(), rr, row, dt,
+                                                 _stream(local)), "tf_allgather_rows")
         return bank
 
     def all_to_all_rows(self, send: torch.Tensor, recv: torch.Tensor, send_rows: Optional[Sequence[int]] = None,

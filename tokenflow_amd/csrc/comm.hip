@@ -146,6 +146,29 @@ extern "C" int tf_allgather_kv(tf_comm* comm, const void* local, void* bank, int
     return 0;
 }
 
+extern "C" int tf_allgather_rows(tf_comm* comm, const void* local, void* bank, const int64_t* rows, int64_t row_elems,
+                                 int dtype, void* stream) {
+    TF_ARG(comm && local && bank && rows, TF_ERR_NULL, "tf_allgather_rows: null pointer");
+    TF_ARG(dtype == TF_BF16 || dtype == TF_F16 || dtype == TF_F32, TF_ERR_DTYPE, "tf_allgather_rows: dtype %d", dtype);
+    TF_ARG(row_elems > 0, TF_ERR_SHAPE, "tf_allgather_rows: row_elems=%lld", (long long)row_elems);
+    for (int p = 0; p < comm->world; ++p)
+        TF_ARG(rows[p] >= 0, TF_ERR_SHAPE, "tf_allgather_rows: negative row count, peer %d", p);
+    TF_NEED_RCCL("tf_allgather_rows");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t rb = (size_t)row_elems * elem_bytes(dtype);
+    const size_t mine = (size_t)rows[comm->rank] * rb;
+    char* r = static_cast<char*>(bank);
+    TF_NCCL(R.GroupStart(), "tf_allgather_rows");
+    ncclResult_t first = ncclSuccess;
+    for (int p = 0; p < comm->world; ++p) {   // every peer (self included) gets this rank's rows; theirs land in rank order
+        if (mine) TF_NCCL_IN_GROUP(R.Send(local, mine, ncclUint8, p, comm->comm, st), first);
+        if (rows[p]) TF_NCCL_IN_GROUP(R.Recv(r, (size_t)rows[p] * rb, ncclUint8, p, comm->comm, st), first);
+        r += (size_t)rows[p] * rb;
+    }
+    TF_NCCL_GROUP_END(first, "tf_allgather_rows");
+    return 0;
+}
+
 extern "C" int tf_all_to_all_rows(tf_comm* comm, const void* send, void* recv, const int64_t* send_rows,
                                   const int64_t* recv_rows, int64_t row_elems, int dtype, void* stream) {
     TF_ARG(comm && send && recv && send_rows && recv_rows, TF_ERR_NULL, "tf_all_to_all_rows: null pointer");

@@ -70,7 +70,9 @@ struct AttnParams {
     int out_f32;       // TF_ATTN_OUT_F32: `out` is float (the normalised fp32 accumulator, no 16-bit rounding)
     int nseg;          // > 1: every bank problem is split into nseg runs of bank frames (small grids, see split_plan)
     float* partials;   // [2 banks][Kq][H][S][nseg][Dh + 8] fp32: unnormalised O, l, log2-domain shift  // K bank frames; queries = frames q_frame0 .. +Kq
-    int64_t ld;
+    int64_t ld;      // token stride of k and v
+    int64_t ld_q;    // token stride of q (its own: a rank's q may be a column slab of the fused projection while the
+                     // bank arrives from a collective as dense slabs)
     // branch / frame strides in elements (dense tensors: frame = S*ld, branch = frames*S*ld; out: S*H*Dh, Kq*S*H*Dh).
     // A caller whose q / k / v arrive from a collective reads them in the layout the collective delivers and has
     // the output written in the layout the next collective sends (tf_ext_attn_fwd_strided, sharded.py).
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     for (int qi = 0; qi < QT; ++qi) {
         q_row[qi] = qt * (32 * QT * NW) + (wave * QT + qi) * 32 + l31;
         q_ok[qi] = q_row[qi] < S;
-        const E* qp = qg + bq * p.q_bs + f * p.q_fs + (int64_t)(q_ok[qi] ? q_row[qi] : S - 1) * p.ld + h * DH;
+        const E* qp = qg + bq * p.q_bs + f * p.q_fs + (int64_t)(q_ok[qi] ? q_row[qi] : S - 1) * p.ld_q + h * DH;
 #pragma unroll
         for (int t = 0; t < C::KS; ++t) {
             const int col = 16 * t + 8 * hi;
@@ -859,7 +861,7 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
     for (int qi = 0; qi < 2; ++qi) {
         q_row[qi] = qt * 256 + (wave * 2 + qi) * 32 + l31;
         q_ok[qi] = q_row[qi] < S;
-        const E* qp = qg + bq * p.q_bs + f * p.q_fs + (int64_t)(q_ok[qi] ? q_row[qi] : S - 1) * p.ld + h * DH;
+        const E* qp = qg + bq * p.q_bs + f * p.q_fs + (int64_t)(q_ok[qi] ? q_row[qi] : S - 1) * p.ld_q + h * DH;
 #pragma unroll
         for (int t = 0; t < C::KS; ++t) {
             const int col = 16 * t + 8 * hi;
@@ -1147,7 +1149,8 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
 // exclude an overflow; when the shift moves, O -- which by then includes the P.V of the half tile that ran beside
 // the softmax, computed against the OLD shift -- is rescaled at the END of the phase, before any P at the new
 // shift is multiplied in (cdna_hip_programming.md T13: scale everything still at the old maximum exactly once).
-// Scope: S a multiple of 64, no split form, MODE_ALL / MODE_SOURCE problems (the dual-V form has its own kernel).
+// Scope: S a multiple of 64, MODE_ALL / MODE_SOURCE problems (the dual-V form has its own kernel); the split form
+// of small grids (runs of bank frames + attn_merge_kernel) as in ext_attn_kernel.
 template <typename T, int MODE, int MINW>
 __global__ __launch_bounds__(512, MINW) void ext_attn_il40_kernel(AttnParams p) {
     constexpr int DH = 40;
@@ -1176,9 +1179,13 @@ __global__ __launch_bounds__(512, MINW) void ext_attn_il40_kernel(AttnParams p) 
     const int h = blockIdx.x % H;
     int u = blockIdx.x / H;
     int b, f, qt;
+    int seg = 0;   // split form (small grids): run of bank frames this workgroup covers, see ext_attn_kernel
+    const int nseg = MODE == MODE_SOURCE ? 1 : p.nseg;
     if constexpr (MODE == MODE_ALL) {
-        const int nbank = 2 * Kq * p.nQT;
+        const int nbank = 2 * Kq * p.nQT * nseg;
         if (u < nbank) {
+            seg = u % nseg;
+            u /= nseg;
             b = 1 + u / (Kq * p.nQT);
             u -= (b - 1) * Kq * p.nQT;
         } else {
@@ -1191,8 +1198,9 @@ __global__ __launch_bounds__(512, MINW) void ext_attn_il40_kernel(AttnParams p) 
     f = u / p.nQT;
     qt = u - f * p.nQT;
     const int bq = (p.inject && b > 0) ? 0 : b;
-    const int f_lo = b == 0 ? p.q_frame0 + f : 0;
-    const int n_fr = b == 0 ? 1 : K;
+    const bool split = nseg > 1 && b > 0;
+    const int f_lo = b == 0 ? p.q_frame0 + f : (seg * K) / nseg;
+    const int n_fr = b == 0 ? 1 : ((seg + 1) * K) / nseg - f_lo;
     const int tpf = S >> 6;
     const int ntiles = n_fr * tpf;
 
@@ -1211,7 +1219,7 @@ __global__ __launch_bounds__(512, MINW) void ext_attn_il40_kernel(AttnParams p) 
     const bool q_ok = q_row < S;
     vec8 qf[C::KS];
     {
-        const E* qp = qg + bq * p.q_bs + f * p.q_fs + (int64_t)(q_ok ? q_row : S - 1) * p.ld + h * DH;
+        const E* qp = qg + bq * p.q_bs + f * p.q_fs + (int64_t)(q_ok ? q_row : S - 1) * p.ld_q + h * DH;
 #pragma unroll
         for (int t = 0; t < C::KS; ++t) {
             const int col = 16 * t + 8 * hi;
@@ -1430,7 +1438,30 @@ __global__ __launch_bounds__(512, MINW) void ext_attn_il40_kernel(AttnParams p) 
     // ---- epilogue
     const float l_tot = __shfl(o[C::MT - 1][ONES_R], l31);   // row DH of the V^T image is 1.0: sum of P from the MFMA
     const float inv_l = 1.0f / l_tot;
-    if (q_ok) {
+    if (split) {
+        // split form: unnormalised O, denominator and shift (log2 domain) of this run of frames for attn_merge_kernel
+        if (q_ok) {
+            constexpr int PS = DH + 8;
+            const int64_t R = (((int64_t)(b - 1) * Kq + f) * H + h) * S + q_row;
+            float* row = p.partials + (R * nseg + seg) * PS;
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int d0 = mt * 32 + 8 * rg + 4 * hi;
+                    if (d0 < DH) {
+                        f32x4 w;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) w[i] = o[mt][rg * 4 + i];
+                        *reinterpret_cast<f32x4*>(row + d0) = w;
+                    }
+                }
+            if (hi == 0) {
+                row[DH] = l_tot;
+                row[DH + 1] = m_run * c;
+            }
+        }
+    } else if (q_ok) {
         const int64_t op = b * p.o_bs + f * p.o_fs + (int64_t)q_row * (H * DH) + h * DH;
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt)
@@ -1456,7 +1487,8 @@ int launch_il40(AttnParams p, hipStream_t st) {
                               (int)lds);
     p.nQT = (p.S + 255) / 256;
     const int per_branch = p.Kq * p.nQT * p.H;
-    const unsigned grid = (unsigned)(MODE == MODE_ALL ? (p.part == TF_ATTN_BANK_ONLY ? 2 : 3) * per_branch : per_branch);
+    const unsigned grid = (unsigned)(MODE == MODE_ALL ? (2 * p.nseg + (p.part == TF_ATTN_BANK_ONLY ? 0 : 1)) * per_branch
+                                                      : per_branch);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
     TF_LAUNCH_CHECK("tf_ext_attn_fwd");
     return 0;
@@ -1547,7 +1579,7 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
         const bool big = p.S >= 256 && (int64_t)3 * p.Kq * ((p.S + 255) / 256) * p.H * p.nseg >= 768;
         if (!p.fold) {   // fp32 score scaling: the default
 #ifndef TF_TUNE_NO_IL40
-            const bool il = big && p.S % 64 == 0 && p.nseg == 1;   // half-tile interleaved form (ext_attn_il40_kernel)
+            const bool il = big && p.S % 64 == 0;   // half-tile interleaved form (ext_attn_il40_kernel)
 #else
             const bool il = false;
 #endif
@@ -1621,8 +1653,12 @@ extern "C" int tf_ext_attn_fwd_strided(const void* q, const void* k, const void*
            "tf_ext_attn_fwd: K=%d S=%d H=%d ld=%lld (ld a multiple of 8, >= H*Dh)", K, S, H, (long long)ld);
     TF_ARG(Kq > 0 && q_frame0 >= 0 && q_frame0 + Kq <= K, TF_ERR_SHAPE,
            "tf_ext_attn_fwd: query frames [%d, %d) outside the %d-frame bank", q_frame0, q_frame0 + Kq, K);
+    const int64_t ld_q = strides[8];
+    TF_ARG(ld_q >= (int64_t)H * Dh && ld_q % 8 == 0, TF_ERR_SHAPE,
+           "tf_ext_attn_fwd: q token stride %lld (a multiple of 8, >= H*Dh)", (long long)ld_q);
     for (int i = 0; i < 8; ++i)
-        TF_ARG(strides[i] % 8 == 0 && (i & 1 ? strides[i] >= (int64_t)(S - 1) * (i < 6 ? ld : (int64_t)H * Dh) : true),
+        TF_ARG(strides[i] % 8 == 0 &&
+                   (i & 1 ? strides[i] >= (int64_t)(S - 1) * (i < 2 ? ld_q : i < 6 ? ld : (int64_t)H * Dh) : true),
                TF_ERR_SHAPE, "tf_ext_attn_fwd: stride %d = %lld (multiples of 8 elements; a frame holds S token rows)", i,
                (long long)strides[i]);
     TF_ARG(tf_aligned16(q) && tf_aligned16(k) && tf_aligned16(v) && tf_aligned16(out) && tf_aligned16(ws),
@@ -1654,6 +1690,7 @@ extern "C" int tf_ext_attn_fwd_strided(const void* q, const void* k, const void*
     TF_ARG(p.part != (TF_ATTN_BANK_ONLY | TF_ATTN_SOURCE_ONLY), TF_ERR_SHAPE,
            "tf_ext_attn_fwd: TF_ATTN_BANK_ONLY and TF_ATTN_SOURCE_ONLY exclude each other");
     p.ld = ld;
+    p.ld_q = ld_q;
     p.q_bs = strides[0];
     p.q_fs = strides[1];
     p.k_bs = strides[2];
@@ -1672,7 +1709,7 @@ extern "C" int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void
                                size_t ws_bytes, void* stream) {
     // dense [3, frames, S, ld] tensors; out [3, Kq, S, H*Dh]
     const int64_t fs = (int64_t)S * ld, ofs = (int64_t)S * H * Dh;
-    const int64_t strides[8] = {Kq * fs, fs, K * fs, fs, K * fs, fs, Kq * ofs, ofs};
+    const int64_t strides[9] = {Kq * fs, fs, K * fs, fs, K * fs, fs, Kq * ofs, ofs, ld};
     return tf_ext_attn_fwd_strided(q, k, v, out, K, Kq, q_frame0, S, H, Dh, ld, strides, scale, inject, dtype, ws,
                                    ws_bytes, stream);
 }

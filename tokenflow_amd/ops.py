@@ -89,14 +89,16 @@ NO_SPLIT = os.environ.get("TOKENFLOW_ATTN_NO_SPLIT", "0") not in ("", "0")
 def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float,
              inject: bool, out: Optional[torch.Tensor] = None, q_frame0: int = 0,
              fold_scale: Optional[bool] = None, part: str = "all",
-             out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+             out_dtype: Optional[torch.dtype] = None, no_split: Optional[bool] = None) -> torch.Tensor:
     """Extended attention core (tokenflow_utils.py:124-197).  k,v: [3K,S,D] bf16/f16 (the bank),
     q: [3Kq,S,D] = the queries of keyframes q_frame0..q_frame0+Kq-1 (Kq = K on one GPU); last dim
     contiguous, equal token stride (q, k, v may be column slabs of one fused projection output).
     Returns [3Kq,S,D] in the same dtype, or in fp32 with out_dtype=torch.float32 (the normalised fp32
     accumulator, no 16-bit output rounding).
     part = "bank": only the uncond/cond branches are computed (the source slabs of v and out, and those
-    of q, k that the call does not read, are never touched); part = "source": only the source branch."""
+    of q, k that the call does not read, are never touched); part = "source": only the source branch.
+    no_split: True = one pass per bank problem whatever the grid (TF_ATTN_NO_SPLIT: arithmetic independent of the
+    grid size), False = let small grids split the bank over workgroups and merge; None = the module default."""
     dev = _need_gpu(q, k, v, out)
     lib = _lib.load()
     B, S, D = k.shape
@@ -129,7 +131,7 @@ def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scal
     if out_dtype == torch.float32:
         flags |= _lib.TF_ATTN_OUT_F32
     flags |= {"all": 0, "bank": _lib.TF_ATTN_BANK_ONLY, "source": _lib.TF_ATTN_SOURCE_ONLY}[part]
-    if NO_SPLIT:
+    if NO_SPLIT if no_split is None else no_split:
         flags |= _lib.TF_ATTN_NO_SPLIT
     key = (K, S, heads, dh, dt)
     nbytes = _attn_ws_bytes.get(key)
@@ -152,12 +154,12 @@ def _view_base(t: torch.Tensor, b0: int, S: int, what: str):
 
 def ext_attn_views(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, heads: int, scale: float,
                    inject: bool, part: str = "all", branch0=(0, 0, 0, 0), q_frame0: int = 0,
-                   fold_scale: Optional[bool] = None) -> torch.Tensor:
+                   fold_scale: Optional[bool] = None, no_split: Optional[bool] = None) -> torch.Tensor:
     """`ext_attn` on strided 4-D views [branches, frames, S, D] (tf_ext_attn_fwd_strided): q, k, v are read where
     a collective left them and `out` is written where the next one sends from -- no re-layout copies.  Each view
     holds the branches `branch0[i] ..` of its tensor (q, k, v, out in that order; e.g. a bank-only call passes the
     uncond/cond slabs with branch0 = 1, and under injection the single source slab of q and k with branch0 = 0).
-    Branch and frame strides are free, the token stride must be the same for q, k, v and dense (= D) for out."""
+    Branch and frame strides are free; k and v share one token stride, q has its own, out is dense (= D)."""
     dev = _need_gpu(q, k, v, out)
     lib = _lib.load()
     S, D = k.shape[2], k.shape[3]
@@ -165,17 +167,17 @@ def ext_attn_views(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch
     dt = _DT.get(q.dtype)
     if dt is None or dt == _lib.TF_F32 or k.dtype != q.dtype or v.dtype != q.dtype or D % heads:
         raise TypeError("ext_attn_views: q/k/v must share dtype bf16 or f16")
-    qp, q_bs, q_fs, ld = _view_base(q, branch0[0], S, "q")
-    kp, k_bs, k_fs, ld_k = _view_base(k, branch0[1], S, "k")
+    qp, q_bs, q_fs, ld_q = _view_base(q, branch0[0], S, "q")
+    kp, k_bs, k_fs, ld = _view_base(k, branch0[1], S, "k")
     vp, v_bs, v_fs, ld_v = _view_base(v, branch0[2], S, "v")
     op, o_bs, o_fs, ld_o = _view_base(out, branch0[3], S, "out")
-    if ld_k != ld or ld_v != ld or ld_o != D or out.shape[1] != Kq or v.shape[1] != K:
-        raise ValueError("ext_attn_views: q, k, v need one token stride, out a dense one; frames of v = frames of k")
+    if ld_v != ld or ld_o != D or out.shape[1] != Kq or v.shape[1] != K:
+        raise ValueError("ext_attn_views: k and v need one token stride, out a dense one; frames of v = frames of k")
     if out.dtype not in (q.dtype, torch.float32):
         raise TypeError("ext_attn_views: out dtype")
     flags = (1 if inject else 0) | (_lib.TF_ATTN_FOLD_SCALE if (FOLD_SCALE if fold_scale is None else fold_scale) else 0)
     flags |= {"all": 0, "bank": _lib.TF_ATTN_BANK_ONLY, "source": _lib.TF_ATTN_SOURCE_ONLY}[part]
-    if NO_SPLIT:
+    if NO_SPLIT if no_split is None else no_split:
         flags |= _lib.TF_ATTN_NO_SPLIT
     if out.dtype == torch.float32:
         flags |= _lib.TF_ATTN_OUT_F32
@@ -184,7 +186,7 @@ def ext_attn_views(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch
     if nbytes is None:
         nbytes = _attn_ws_bytes[key] = lib.tf_ext_attn_workspace_bytes(K, S, heads, dh, dt)
     ws = _workspace(nbytes, q.device)
-    strides = (ctypes.c_int64 * 8)(q_bs, q_fs, k_bs, k_fs, v_bs, v_fs, o_bs, o_fs)
+    strides = (ctypes.c_int64 * 9)(q_bs, q_fs, k_bs, k_fs, v_bs, v_fs, o_bs, o_fs, ld_q)
     _launch(dev, "tf_ext_attn_fwd_strided", lib.tf_ext_attn_fwd_strided, qp, kp, vp, op, K, Kq, int(q_frame0), S, heads,
             dh, ld, ctypes.cast(strides, ctypes.c_void_p), float(scale), flags, dt, ws.data_ptr(), ws.numel())
     return out

@@ -21,12 +21,14 @@ side stream ordered against the compute stream with events):
         connected xGMI mesh every pair uses its own link.  The source branch (own-frame
         keys only, 173/177) never leaves the rank: `ops.ext_attn(part="source")` runs on the
         local frames while the first exchange is in flight.
-    "bank": all-gather of the key/value bank.  Only what is read remotely travels: without
-        injection K and V of uncond and cond (4 slabs of [K/W,S,D] per rank, gathered to
-        [K,S,D]); with injection 3 slabs.  Each slab is gathered straight into its place in
-        the [3,K,S,D] bank the kernel reads; `ops.ext_attn(q_local, k_bank, v_bank,
-        q_frame0=...)` then computes only the local keyframes' queries.  A rank receives
-        4*(W-1) local slabs: 4x the "heads" volume at W = 8, and ring-bound.
+    "bank": ONE all-gather of the key/value slabs of the local keyframes (6 slabs of [K/W,S,D]
+        per rank; 4 with injection), packed by one launch and gathered straight into the
+        [K,slabs,S,D] buffer that ONE `ops.ext_attn_views(q_local, k_bank, v_bank, q_frame0=...)`
+        call reads in place, computing only the local keyframes' queries.  A rank receives
+        6*(W-1) local slabs -- several times the "heads" volume at W = 8 -- for one collective,
+        one pack and one attention call per block instead of two collectives, pack, unpack and two
+        calls: chosen per block (`auto_mode`) where the exchange is latency-bound (the mid block),
+        and whenever the heads do not divide over the ranks.
 
  2. propagation passes -- chunk c needs keyframes c and c-1 (331-333): the first local chunk's
     left neighbour lives on rank r-1, so each rank sends its LAST keyframe's pivot features,
@@ -34,11 +36,14 @@ side stream ordered against the compute stream with events):
 
 Work is partitioned, not re-associated: every output element is produced by exactly the same
 kernel arithmetic as on one GPU (the attention of one (query, head) visits the K frames in the
-same order, whoever computes it), so sharded results equal single-process results bit for bit --
-with one exception: the small grid of a rank makes `tf_ext_attn_fwd` split the bank over extra
-workgroups and merge, which re-associates fp32 sums; TOKENFLOW_ATTN_NO_SPLIT=1
-turns that off and restores bit-identical results.
+same order, whoever computes it), so sharded results equal single-process results bit for bit.
+That is the default: `FrameShard` asks the attention for its one-pass form (TF_ATTN_NO_SPLIT),
+whose arithmetic does not depend on the grid.  `FrameShard(..., attn_split=True)` (or
+TOKENFLOW_SHARD_ATTN_SPLIT=1) lets the small grid of a rank split the bank over extra workgroups
+and merge: faster, and equal to the single-GPU result only within the output
+rounding, because the merge re-associates fp32 sums.
 """
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -80,7 +85,15 @@ class FrameShard:
     """K keyframes (= chunks) over the ranks of `group` in contiguous runs; the first K % W ranks hold one more
     (cfg5's 25 chunks over 8 ranks -> 4,3,3,3,3,3,3,3)."""
 
-    def __init__(self, K: int, group: Optional[dist.ProcessGroup] = None, comm=None):
+    def __init__(self, K: int, group: Optional[dist.ProcessGroup] = None, comm=None,
+                 attn_split: Optional[bool] = None):
+        # attn_split: let the attention split a rank's small grid over extra workgroups and merge (faster: -15..40 %
+        # on a rank's attention at 8 GPUs, DESIGN.md 4.1; results then agree with the single-GPU ones within the
+        # output rounding).  Default False: one pass per bank problem, arithmetic independent of the grid, sharded
+        # results equal to single-GPU results bit for bit.  None reads TOKENFLOW_SHARD_ATTN_SPLIT.
+        if attn_split is None:
+            attn_split = os.environ.get("TOKENFLOW_SHARD_ATTN_SPLIT", "0") not in ("", "0")
+        self.attn_split = bool(attn_split)
         self.group = group
         self.comm = comm                       # tokenflow_amd.comm.HipComm: exchanges through the C ABI instead
         self._cs = None                        # its side stream
@@ -141,58 +154,99 @@ class FrameShard:
         return None
 
     # ------------------------------------------------------------------ pivotal pass
-    def gather_bank(self, k_local: torch.Tensor, v_local: torch.Tensor, inject: bool
-                    ) -> Tuple[torch.Tensor, torch.Tensor]:
-        """k_local, v_local: [3*Kl, S, D] -> banks [3*K, S, D] holding every slab the kernel reads."""
-        if self.world == 1:
-            return k_local, v_local
+    def _bank_gather(self, k_local: torch.Tensor, v_local: torch.Tensor, inject: bool):
+        """ONE collective per block: the slabs of the local keyframes that the attention reads across frames --
+        without injection k and v of all three branches ([k0,k1,k2,v0,v1,v2]: the source slabs ride along so that the
+        gathered buffer is the whole [3,K,S,D] bank of ONE attention call), with injection [k0,v0,v1,v2] -- are packed
+        frame-major by one `tf_head_pack` launch (W = 1: a plain slab pack), gathered straight into
+        [K (global frame order), slabs, S, D], and read there in place through strided views.  Runs of different
+        lengths (K % W != 0) use the row form of the all-gather (no padding, no compaction copies).
+        Returns (k view [3 or 1, K, S, D], v view [3, K, S, D])."""
         B, S, D = k_local.shape
         Kl, K, W = self.Kl, self.K, self.world
-        kl, vl = k_local.contiguous().view(3, Kl, S, D), v_local.contiguous().view(3, Kl, S, D)
-        kb = torch.empty(3, K, S, D, dtype=k_local.dtype, device=k_local.device)
-        vb = torch.empty(3, K, S, D, dtype=v_local.dtype, device=v_local.device)
-        sl = slice(self.kf0, self.kf0 + Kl)
-        works, pads = [], []
-        for b in range(3):
-            k_remote = (b == 0) if inject else (b > 0)     # key bank read across frames?
-            v_remote = b > 0
-            for need, bank, loc in ((k_remote, kb, kl), (v_remote, vb, vl)):
-                if not need:
-                    bank[b, sl].copy_(loc[b])               # only this rank's own frames are read
-                elif self.even:                             # straight into place, no re-layout
-                    works.append(self._allgather(bank[b], loc[b]))
-                else:                                       # uneven runs: equal-size padded contributions
-                    Km = self.counts[0]
-                    mine = torch.zeros(Km, S, D, dtype=loc.dtype, device=loc.device)
-                    mine[:Kl].copy_(loc[b])
-                    allp = torch.empty(W * Km, S, D, dtype=loc.dtype, device=loc.device)
-                    works.append(self._allgather(allp, mine))
-                    pads.append((bank[b], allp.view(W, Km, S, D)))
-        for w in works:
-            w.wait()
-        for dst, allp in pads:
-            for r in range(W):
-                dst[self.offsets[r]:self.offsets[r] + self.counts[r]].copy_(allp[r, :self.counts[r]])
-        return kb.view(3 * K, S, D), vb.view(3 * K, S, D)
+        dev, dt = k_local.device, k_local.dtype
 
-    def _allgather(self, bank: torch.Tensor, mine: torch.Tensor):
+        def frames(t):     # [3*Kl, S, D] (token stride free) -> [3, Kl, S, D] view
+            if t.stride(2) != 1 or t.stride(0) != S * t.stride(1):
+                t = t.contiguous()
+            return t.view(3, Kl, S, D) if t.is_contiguous() else t.unflatten(0, (3, Kl))
+        k3, v3 = frames(k_local), frames(v_local)
+        if k3.stride(2) != v3.stride(2):
+            k3, v3 = k3.contiguous(), v3.contiguous()
+        slabs = [k3[0], v3[0], v3[1], v3[2]] if inject else [k3[0], k3[1], k3[2], v3[0], v3[1], v3[2]]
+        ns = len(slabs)
+        send = ops.head_pack(slabs, 1, out=self._buf("bank_send", (1, Kl, ns, S, D), dt, dev)).view(Kl, ns * S * D)
+        recv = self._buf("bank_recv", (K, ns * S * D), dt, dev)
         comm = getattr(self, "comm", None)
-        if comm is None:
-            return dist.all_gather_into_tensor(bank, mine, group=self.group, async_op=True)
-        return self._side([bank, mine], lambda: comm.allgather(mine, bank))
+        if self.even:
+            if comm is None:
+                if send.is_cuda and dist.get_backend(self.group) == "gloo":     # development boxes: host staging
+                    host = torch.empty(recv.shape, dtype=dt)
+                    dist.all_gather_into_tensor(host, send.cpu(), group=self.group)
+                    recv.copy_(host)
+                else:
+                    dist.all_gather_into_tensor(recv, send, group=self.group)
+            else:
+                self._side([recv, send], lambda: comm.allgather(send, recv)).wait()
+        elif comm is None:       # one grouped point-to-point exchange: my rows to every peer, theirs into place
+            staged = send.is_cuda and dist.get_backend(self.group) == "gloo"
+            src = send.cpu() if staged else send
+            dst = torch.empty(recv.shape, dtype=dt) if staged else recv
+            opsl = []
+            for r in range(W):
+                if r == self.rank:
+                    continue
+                peer = self._peer(r)
+                opsl.append(dist.P2POp(dist.isend, src, peer, self.group))
+                opsl.append(dist.P2POp(dist.irecv, dst[self.offsets[r]:self.offsets[r] + self.counts[r]], peer,
+                                       self.group))
+            reqs = dist.batch_isend_irecv(opsl)
+            dst[self.kf0:self.kf0 + Kl].copy_(src)
+            for r in reqs:
+                r.wait()
+            if staged:
+                recv.copy_(dst)
+        else:
+            self._side([recv, send], lambda: comm.allgather_rows(send, recv, self.counts)).wait()
+        rp = recv.view(K, ns, S, D).permute(1, 0, 2, 3)        # [ns, K, S, D] views: frame stride ns*S*D
+        return (rp[0:1], rp[1:4]) if inject else (rp[0:3], rp[3:6])
+
+    def auto_mode(self, heads: int, S: int) -> str:
+        """Exchange pattern of the pivotal pass for one block.  "heads" moves the least data (under 8 local slabs
+        per rank whatever W) and is the choice wherever the block has real work; it needs heads % W == 0.  "bank"
+        is ONE collective and ONE attention call instead of two collectives, a pack, an unpack and two calls: the
+        choice where a block is a few tens of microseconds of work (S <= 64: the mid block) and the exchange is
+        latency-, not volume-bound -- and the only one when the heads do not divide over the ranks."""
+        if heads % self.world:
+            return "bank"
+        return "bank" if S <= 64 else "heads"
 
     def pivotal_attention(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool,
                           mode: Optional[str] = None):
         """Extended attention for the local keyframes against all K keyframes -> [3*Kl,S,D].
-        mode: "heads" | "bank" | None (= "heads" when the heads divide over the ranks)."""
+        mode: "heads" | "bank" | None (= `auto_mode`, chosen per block)."""
         if self.world == 1:
             return ops.ext_attn(q_local, k_local, v_local, heads, scale, inject)
         if mode is None:
-            mode = "heads" if heads % self.world == 0 else "bank"
+            mode = self.auto_mode(heads, q_local.shape[1])
         if mode == "heads":
             return self._pivotal_heads(q_local, k_local, v_local, heads, scale, inject)
-        kb, vb = self.gather_bank(k_local, v_local, inject)
-        return ops.ext_attn(q_local, kb, vb, heads, scale, inject, q_frame0=self.kf0)
+        return self._pivotal_bank(q_local, k_local, v_local, heads, scale, inject)
+
+    def _pivotal_bank(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool):
+        """One gather (`_bank_gather`), one attention call on the gathered buffer in place; q keeps its own layout
+        (its token stride is independent of the bank's)."""
+        B, S, D = q_local.shape
+        Kl = self.Kl
+        kv, vv = self._bank_gather(k_local, v_local, inject)
+        q = q_local
+        if q.stride(2) != 1 or q.stride(0) != S * q.stride(1):
+            q = q.contiguous()
+        q4 = q.view(3, Kl, S, D) if q.is_contiguous() else q.unflatten(0, (3, Kl))
+        out = torch.empty(3, Kl, S, D, dtype=q.dtype, device=q.device)
+        ops.ext_attn_views(q4, kv, vv, out, heads, scale, inject, "all", q_frame0=self.kf0,
+                           no_split=not self.attn_split)
+        return out.view(3 * Kl, S, D)
 
     def _pivotal_heads(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool):
         """Frames <-> heads re-sharding.  Launches per block on this rank: ONE pack kernel, the source-branch
@@ -227,16 +281,19 @@ class FrameShard:
                          None if even else self.counts, None if even else [Kl] * W, async_op=True)
         # ---- source branch: own-frame keys, all heads, stays local (overlaps the exchange)
         out = torch.empty(3, Kl, S, D, dtype=dt, device=dev)
-        ops.ext_attn(q_local, k_local, v_local, heads, scale, inject, out=out.view(3 * Kl, S, D), part="source")
+        ops.ext_attn(q_local, k_local, v_local, heads, scale, inject, out=out.view(3 * Kl, S, D), part="source",
+                     no_split=not self.attn_split)
         work.wait()
         # ---- bank branches on this rank's head group, all K frames: read `recv`, write `send2`, both in place
         rp = recv.permute(1, 0, 2, 3)                                   # [ns, K, S, hd] view
         send2 = self._buf("send2", (K, 2, S, hd), dt, dev)            # [frame][uncond|cond]: rows of rank w's run -> w
         o4 = send2.permute(1, 0, 2, 3)                                  # [2, K, S, hd] view = branches 1, 2
         if inject:
-            ops.ext_attn_views(rp[0:1], rp[1:2], rp[2:4], o4, heads // W, scale, True, "bank", branch0=(0, 0, 1, 1))
+            ops.ext_attn_views(rp[0:1], rp[1:2], rp[2:4], o4, heads // W, scale, True, "bank", branch0=(0, 0, 1, 1),
+                               no_split=not self.attn_split)
         else:
-            ops.ext_attn_views(rp[0:2], rp[2:4], rp[4:6], o4, heads // W, scale, False, "bank", branch0=(1, 1, 1, 1))
+            ops.ext_attn_views(rp[0:2], rp[2:4], rp[4:6], o4, heads // W, scale, False, "bank", branch0=(1, 1, 1, 1),
+                               no_split=not self.attn_split)
         # ---- outputs back to the frame owners
         recv2 = self._buf("recv2", (W, Kl, 2, S, hd), dt, dev)        # [head group][my frames][uncond|cond]
         self._a2a(recv2.view(W * Kl, -1), send2.view(K, -1),
