@@ -17,8 +17,10 @@ injection is on for every other step (the reference injects during the first 50 
 config_pnp.yaml:21); the two states are also timed separately (`ms_per_step_inject_on/off`).
 
 N > 1: frames are sharded over ranks (tokenflow_amd/sharded.py): the SAME video is split, so scaling is "strong";
-the pivotal-pass exchange (frames <-> heads all-to-all, or the bank all-gather with --pivotal-exchange bank) and
-the neighbour halo exchange run through torch.distributed (RCCL) inside the timed region.
+the pivotal-pass exchange (frames <-> heads all-to-all or the single-collective bank all-gather, chosen per block;
+--pivotal-exchange forces one) and the neighbour halo exchange run through torch.distributed (RCCL) inside the
+timed region.  The step then follows the reference's call order: the pivotal pass over all 16 blocks, then the
+propagation of all blocks (the halo of a block travels under the rest of the pivotal pass).
 
 Prints ONE JSON line (rank 0):
   roofline      the dominant kernel: the head-dim-40 extended attention of level 0 WITHOUT q/k injection
@@ -68,6 +70,10 @@ def parse():
                          "the library's C ABI (tf_comm_*: RCCL without torch.distributed on the data path; gloo carries "
                          "only the barrier and the unique id); gloo lets several ranks share one GPU on a development "
                          "box (functional check of the N > 1 path, its timing means nothing)")
+    ap.add_argument("--no-attn-split", action="store_true",
+                    help="N > 1: keep the rank's attention in its one-pass form (FrameShard's default: bit-identical to "
+                         "the single-GPU result).  By default the bench lets a rank's small grid split the bank over "
+                         "extra workgroups and merge (attn_split=True: faster, equal within the output rounding)")
     ap.add_argument("--per-chunk", action="store_true",
                     help="issue the propagation one call per chunk (the reference's granularity) instead of one "
                          "call per block over all chunks")
@@ -113,6 +119,8 @@ class Block:
 def run_step(cfg, blocks, shard, inject_on, w, events=None, exchange=None, per_chunk=False):
     n = cfg.chunk
     outs = None
+    two_pass = shard.world > 1 and not per_chunk
+    pending = []
     for blk in blocks:
         inj = inject_on and blk.injected and cfg.pnp
         timed = events is not None and blk.lvl == 0
@@ -131,6 +139,12 @@ def run_step(cfg, blocks, shard, inject_on, w, events=None, exchange=None, per_c
         if timed:
             e1.record()
             events.append((e0, e1, inj))
+        if two_pass:
+            # N > 1: the reference's own call order (run_tokenflow_pnp.py:222-231) -- ONE pivotal UNet pass over all 16
+            # blocks, then the chunk passes.  The attention-output halo of every block is sent as soon as it exists and
+            # has the rest of the pivotal pass to arrive; nothing waits for the wire until the propagation reads it.
+            pending.append((blk, shard.halo_finish(halo, kf_out, wait=False)))
+            continue
         if per_chunk or shard.world == 1:
             if halo is None:
                 piv_e, inv_e, kfo_e = shard.exchange_halo(blk.pivots, ops.pivot_inv_norm(blk.pivots), kf_out)
@@ -142,12 +156,10 @@ def run_step(cfg, blocks, shard, inject_on, w, events=None, exchange=None, per_c
             for j in range(shard.Kl):
                 outs = shard.propagate(j, blk.tgt[j * nS:(j + 1) * nS], res[:, j].reshape(3 * n, blk.S, blk.D),
                                        piv_e, inv_e, kfo_e, w, n)
-        elif shard.world == 1:
-            outs = shard.propagate_all(blk.tgt, blk.res, piv_e, inv_e, kfo_e, w, n)
         else:
-            # the attention-output halo travels under the propagation of the local chunks that do not read it
-            piv_e, inv_e, kfo_e, reqs = shard.halo_finish(halo, kf_out, wait=False)
-            outs, _ = shard.propagate_all(blk.tgt, blk.res, piv_e, inv_e, kfo_e, w, n, halo_reqs=reqs)
+            outs = shard.propagate_all(blk.tgt, blk.res, piv_e, inv_e, kfo_e, w, n)
+    for blk, (piv_e, inv_e, kfo_e, reqs) in pending:
+        outs, _ = shard.propagate_all(blk.tgt, blk.res, piv_e, inv_e, kfo_e, w, n, halo_reqs=reqs)
     return outs
 
 
@@ -428,16 +440,16 @@ def main():
         uid = [HipComm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)          # control plane only: the tensors never touch gloo
         hip_comm = HipComm(uid[0], rank, world)
-    shard = sharded.FrameShard(cfg.K, comm=hip_comm)
+    shard = sharded.FrameShard(cfg.K, comm=hip_comm, attn_split=world > 1 and not args.no_attn_split)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     blocks = [Block(cfg, lvl, inj, shard, gen, dev) for lvl, inj in workload.BLOCKS]
     w = blend_w(cfg.chunk, dev)
     exchange = None if args.pivotal_exchange == "auto" else args.pivotal_exchange
-    n_heads_ok = sum(1 for l in cfg.levels if l[2] % world == 0)
-    names = {"heads": "frames<->heads all-to-all", "bank": "K/V bank all-gather"}
-    exch_name = (names[exchange] if exchange else names["heads"] if n_heads_ok == len(cfg.levels)
-                 else names["bank"] if n_heads_ok == 0
-                 else "frames<->heads all-to-all on the levels whose heads divide over the ranks, K/V bank all-gather on the others")
+    names = {"heads": "frames<->heads all-to-all", "bank": "K/V bank all-gather (one collective)"}
+    modes = [exchange or shard.auto_mode(l[2], l[0]) for l in cfg.levels]
+    exch_name = (names[modes[0]] if len(set(modes)) == 1
+                 else "per level " + ", ".join("L%d %s" % (i, m) for i, m in enumerate(modes))
+                 + " (heads = frames<->heads all-to-all, bank = one K/V all-gather)")
     use_graph = args.graph and world == 1   # capturing RCCL calls crashes in hipStreamEndCapture on this stack
 
     def barrier():
@@ -539,8 +551,10 @@ def main():
                    else "one per block over all chunks (tf_nn_gather_blend_chunks)",
                    "launch": "HIP-graph replay" if use_graph else "eager",
                    "parallelism": "1 GPU" if world == 1 else
-                   "frames sharded over %d GPUs; pivotal pass: %s%s" % (
-                       world, exch_name, "; exchanges through the C ABI (tf_comm_*)" if hip_comm is not None else ""),
+                   "frames sharded over %d GPUs; pivotal pass: %s%s; rank attention %s" % (
+                       world, exch_name, "; exchanges through the C ABI (tf_comm_*)" if hip_comm is not None else "",
+                       "split over extra workgroups + merge (equal to 1 GPU within the output rounding)"
+                       if shard.attn_split else "one-pass (bit-identical to 1 GPU)"),
                    "step_algorithmic_tflop": round((fa + fn) / 1e12, 2),
                    "step_tflops_achieved": round((fa + fn) / 1e12 / (ms_per_step * 1e-3), 1)},
         "roofline": plain if plain is not None else dual,

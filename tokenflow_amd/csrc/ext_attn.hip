@@ -1578,8 +1578,13 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
         // workgroups).  S < 256: always 4 waves.
         const bool big = p.S >= 256 && (int64_t)3 * p.Kq * ((p.S + 255) / 256) * p.H * p.nseg >= 768;
         if (!p.fold) {   // fp32 score scaling: the default
+#ifndef TF_TUNE_IL40_MIN_WGS
+#define TF_TUNE_IL40_MIN_WGS 768
+#endif
 #ifndef TF_TUNE_NO_IL40
-            const bool il = big && p.S % 64 == 0;   // half-tile interleaved form (ext_attn_il40_kernel)
+            // half-tile interleaved form (ext_attn_il40_kernel)
+            const bool il = p.S >= 256 && p.S % 64 == 0 &&
+                            (int64_t)3 * p.Kq * ((p.S + 255) / 256) * p.H * p.nseg >= TF_TUNE_IL40_MIN_WGS;
 #else
             const bool il = false;
 #endif

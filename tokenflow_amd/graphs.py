@@ -66,6 +66,12 @@ class GraphCache:
         self._entries.clear()
         self._pool = None
 
+    def inputs(self, key: Hashable) -> Tuple[torch.Tensor, ...]:
+        """The capture's static input tensors of `key`: a producer that writes its results straight into them (and
+        passes them back to `run`) pays no input copy per replay -- inside a real UNet the block inputs are produced
+        by the preceding layers of the same graph and are never copied either."""
+        return self._entries[key].static_in
+
     def run(self, key: Hashable, fn: Callable[..., Any], *inputs: torch.Tensor):
         e = self._entries.get(key)
         if e is None:

@@ -1,0 +1,148 @@
+#!/usr/bin/env python
+"""One rank's share of a cfg2 step at W GPUs (default: rank 1 of 8 -- one keyframe, one chunk, a left neighbour),
+with the wire taken out: `FrameShard` runs on a stand-in comm with HipComm's interface whose exchanges are local
+copies of the same size on the exchange stream, so every launch, buffer, stream hand-over and host call of the real
+rank is there and only the xGMI transfer time is missing.  The step is bench.py's own `run_step` (pivotal pass over
+the 16 blocks, then their propagation: the reference's call order).
+
+Prints, per configuration (attention split on / off, exchange pattern):
+  * the whole rank step: GPU time (events around the asynchronously issued step: what the rank's step costs when the
+    host can run ahead) and host issue time, median / min / max over the repetitions;
+  * per level, in isolation: pivotal pass and propagation of ONE block, GPU and host time, median / max -- isolated
+    blocks of the coarse levels are host-bound (the GPU waits for the next launch), inside a step the host runs ahead
+    during the level-0 blocks;
+  * the bytes a rank would put on the wire per block, and the time they take at an assumed per-link rate.
+Target: step <= single-GPU step / 6."""
+import argparse
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from tokenflow_amd import sharded, workload  # noqa: E402
+
+
+class LocalComm:
+    """HipComm's interface; every exchange is a same-size device copy on the calling stream."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+        self.bytes = 0
+
+    def allgather(self, local, bank):
+        bank.view(self.world, -1).copy_(local.reshape(1, -1).expand(self.world, -1))
+        self.bytes += local.numel() * local.element_size() * (self.world - 1)
+        return bank
+
+    def allgather_rows(self, local, bank, rows):
+        off = 0
+        for p, r in enumerate(rows):
+            bank[off:off + r].copy_(local[:1].expand(r, -1) if r != local.shape[0] else local)
+            off += r
+        self.bytes += local.numel() * local.element_size() * (self.world - 1)
+        return bank
+
+    def all_to_all_rows(self, send, recv, send_rows=None, recv_rows=None):
+        n = min(send.numel(), recv.numel())
+        recv.view(-1)[:n].copy_(send.view(-1)[:n])
+        if recv.numel() > n:
+            recv.view(-1)[n:].copy_(send.view(-1)[:recv.numel() - n])
+        self.bytes += send.numel() * send.element_size() * (self.world - 1) // self.world
+        return recv
+
+    def sendrecv(self, send, send_peer, recv, recv_peer):
+        if recv_peer >= 0:
+            for s, r in zip(send, recv):
+                r.copy_(s)
+        if send_peer >= 0:
+            self.bytes += sum(t.numel() * t.element_size() for t in send)
+
+
+def measure(fn, reps, warm):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    gpu, host = [], []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        t0 = time.perf_counter()
+        fn()
+        host.append((time.perf_counter() - t0) * 1e6)
+        e1.record()
+        torch.cuda.synchronize()
+        gpu.append(e0.elapsed_time(e1) * 1e3)
+    return gpu, host
+
+
+def fmt(xs):
+    return "%8.1f (min %8.1f, max %8.1f)" % (statistics.median(xs), min(xs), max(xs))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--rank", type=int, default=1)
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--link-gbs", type=float, default=50.0, help="assumed achieved rate of one xGMI link, GB/s")
+    ap.add_argument("--single-ms", type=float, default=27.9, help="single-GPU step (driver, round 2)")
+    args = ap.parse_args()
+    cfg = workload.CONFIGS[args.config]
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    w = bench.blend_w(cfg.chunk, dev)
+    for split in (True, False):
+        for mode in (None, "heads", "bank"):
+            comm = LocalComm(args.rank, args.world)
+            shard = sharded.FrameShard(cfg.K, comm=comm, attn_split=split)
+            if mode == "heads" and any(l[2] % args.world for l in cfg.levels):
+                continue
+            gen = torch.Generator(device=dev).manual_seed(1234 + args.rank)
+            blocks = [bench.Block(cfg, lvl, inj, shard, gen, dev) for lvl, inj in workload.BLOCKS]
+            modes = [mode or shard.auto_mode(l[2], l[0]) for l in cfg.levels]
+            print(f"=== rank {args.rank} of {args.world}, {cfg.name}: Kl={shard.Kl}, attention "
+                  f"{'split+merge' if split else 'one-pass (bit-exact)'}, exchange per level {modes}", flush=True)
+            for inj in (False, True):
+                gpu, host = measure(lambda: bench.run_step(cfg, blocks, shard, inj, w, exchange=mode), args.reps, 3)
+                med = statistics.median(gpu)
+                print(f"  step inject={int(inj)}: GPU {fmt(gpu)} us   host issue {fmt(host)} us   -> "
+                      f"{args.single_ms * 1e3 / med:4.2f}x of the {args.single_ms} ms single-GPU step (wire-less)",
+                      flush=True)
+            comm.bytes = 0
+            bench.run_step(cfg, blocks, shard, False, w, exchange=mode)
+            torch.cuda.synchronize()
+            wire_us = comm.bytes / (args.link_gbs * 1e3) / min(args.world - 1, 7)
+            print(f"  wire: {comm.bytes / 1e6:7.1f} MB sent per rank and step; at {args.link_gbs:.0f} GB/s per link over "
+                  f"{min(args.world - 1, 7)} links {wire_us:7.0f} us if nothing overlapped (halo: one link only)")
+            for lvl in range(len(cfg.levels)):
+                blk = next(b for b in blocks if b.lvl == lvl)
+                for inj in ((False, True) if blk.injected or any(b.injected for b in blocks if b.lvl == lvl) else (False,)):
+                    b1 = next((b for b in blocks if b.lvl == lvl and b.injected), blk) if inj else blk
+                    state = {}
+
+                    def pivotal():
+                        scale = (b1.D // b1.h) ** -0.5
+                        halo = shard.halo_start(b1.pivots, bench.ops.pivot_inv_norm(b1.pivots))
+                        kf = shard.pivotal_attention(b1.q, b1.k, b1.v, b1.h, scale, inj, mode=mode)
+                        state["h"] = shard.halo_finish(halo, kf, wait=False)
+
+                    def prop():
+                        pe, ie, ke, reqs = state["h"]
+                        shard.propagate_all(b1.tgt, b1.res, pe, ie, ke, w, cfg.chunk, halo_reqs=reqs)
+                    g1, h1 = measure(pivotal, args.reps, 3)
+                    g2, h2 = measure(prop, args.reps, 3)
+                    print(f"  level {lvl} (S={b1.S}, D={b1.D}) inject={int(inj)} isolated block: pivotal GPU "
+                          f"{statistics.median(g1):7.1f} (max {max(g1):7.1f}) host {statistics.median(h1):6.1f} | "
+                          f"propagation GPU {statistics.median(g2):7.1f} (max {max(g2):7.1f}) host "
+                          f"{statistics.median(h2):6.1f} us", flush=True)
+
+
+if __name__ == "__main__":
+    main()
