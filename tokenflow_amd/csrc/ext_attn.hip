@@ -736,7 +736,10 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
 static int split_plan(int K, int Kq, int S, int H, int Dh, bool inject, int part, bool allow) {
     if (!allow || part == TF_ATTN_SOURCE_ONLY) return 1;
     const bool dual = inject && S >= 256 && Dh != 160;
-    const int occ = Dh == 40 ? (dual ? 3 : 4) : Dh == 160 ? 1 : (dual ? 2 : 3);   // waves per SIMD the kernels reach
+#ifndef TF_TUNE_OCC160
+#define TF_TUNE_OCC160 1
+#endif
+    const int occ = Dh == 40 ? (dual ? 3 : 4) : Dh == 160 ? TF_TUNE_OCC160 : (dual ? 2 : 3);   // waves per SIMD the kernels reach
     const int64_t wgs = (int64_t)(dual ? 1 : 2) * Kq * ((S + 127) / 128) * H;   // 4-wave workgroups
     const int tpf = (S + 63) / 64;
     if (K * tpf < 16) return 1;   // a bank of a few tiles: the merge launch costs more than it buys (8x8 level)
@@ -1133,37 +1136,60 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Half-tile interleaved variant for Dh = 40, fp32 score scaling (the default).
+// Half-tile interleaved variant (fp32 score scaling): Dh = 40 (the cfg2 / cfg3 level-0 form), 80, 160.
 //
-// The plain kernel runs QK^T (6 MFMAs) -> softmax (64 VALU) -> P.V (8 MFMAs) of one 64-key tile back to back:
-// inside a wave the matrix pipe idles during the softmax and the VALU during the MFMAs, and the overlap that four
-// independent waves per SIMD provide stops at ~49 % matrix-pipe utilisation.  Here ONE query tile
-// per wave is software-pipelined over 32-key half tiles, so that every stretch of the instruction stream has
-// INDEPENDENT matrix and vector work, issued alternately (one MFMA, ~5 VALU, pinned by sched_barrier(0)):
-//     phase 1 of tile t:  O += V0(t) P0(t)  and  S0(t+1) = K0(t+1) Q   (7 MFMAs)  ||  P1(t)   = exp2(S1(t) c - m c)
-//     phase 2 of tile t:  O += V1(t) P1(t)  and  S1(t+1) = K1(t+1) Q   (7 MFMAs)  ||  P0(t+1) = exp2(S0(t+1) c - m c)
-// Same registers as the plain kernel (the two 32-key score halves were separate accumulators already), same LDS
-// images, K staged one tile earlier (as in the ping-pong kernel): top of iteration t writes K(t+1) and V(t) from
-// registers loaded an iteration before, one barrier, then the two phases.
-// Online softmax with the score bound (BOUND): a half tile looks at its maximum only when the bound does not
-// exclude an overflow; when the shift moves, O -- which by then includes the P.V of the half tile that ran beside
-// the softmax, computed against the OLD shift -- is rescaled at the END of the phase, before any P at the new
-// shift is multiplied in (cdna_hip_programming.md T13: scale everything still at the old maximum exactly once).
+// The plain kernel runs QK^T -> softmax (64 VALU) -> P.V of one 64-key tile back to back: inside a wave the matrix
+// pipe idles during the softmax and the VALU during the MFMAs, and the overlap that independent waves on a SIMD
+// provide stops at ~49 % matrix-pipe utilisation at Dh = 40 -- and does not exist at all where the
+// registers / LDS of the larger head dims leave one or two waves per SIMD (Dh = 160: 89 KB of tiles per workgroup).
+// Here ONE query tile per wave is software-pipelined over 32-key half tiles, so that every stretch of the
+// instruction stream has INDEPENDENT matrix and vector work, issued alternately (one MFMA, its share of the softmax,
+// pinned by sched_barrier(0)):
+//     phase 1 of tile t:  O += V0(t) P0(t)  and  S0(t+1) = K0(t+1) Q   (2 MT + KS MFMAs)  ||  P1(t)   = exp2(S1(t) c - m c)
+//     phase 2 of tile t:  O += V1(t) P1(t)  and  S1(t+1) = K1(t+1) Q                       ||  P0(t+1) = exp2(S0(t+1) c - m c)
+// (7 MFMAs per phase at Dh = 40, 11 at 80, 20 at 160, against the same 8 softmax units of 2 fma + 2 exp + 1 cvt.)
+// Same LDS images as the plain kernel, K staged one tile earlier (as in the ping-pong kernel): top of iteration t
+// writes K(t+1) and V(t) from registers loaded an iteration before, one barrier, then the two phases.
+// Online softmax: Dh = 40 uses the score bound (BOUND: a half tile looks at its maximum only when the bound does not
+// exclude an overflow); the other head dims take the half tile's maximum every time (they are matrix-bound).  When
+// the shift moves, O -- which by then includes the P.V of the half tile that ran beside the softmax, computed against
+// the OLD shift -- is rescaled at the END of the phase, before any P at the new shift is multiplied in
+// (cdna_hip_programming.md T13: scale everything still at the old maximum exactly once).
 // Scope: S a multiple of 64, MODE_ALL / MODE_SOURCE problems (the dual-V form has its own kernel); the split form
 // of small grids (runs of bank frames + attn_merge_kernel) as in ext_attn_kernel.
-template <typename T, int MODE, int MINW>
-__global__ __launch_bounds__(512, MINW) void ext_attn_il40_kernel(AttnParams p) {
-    constexpr int DH = 40;
+template <int MT, int KS, bool NEXT>
+struct IlSchedule {   // MFMA order of one phase: QK^T k-steps (one accumulator chain) alternate with the P.V MFMAs
+    static constexpr int N = (NEXT ? KS : 0) + 2 * MT;   // (M-tile round-robin, 2 k-steps): never two MFMAs on one
+    int is_pv[N] = {}, a[N] = {}, b[N] = {};              // accumulator next to each other
+    constexpr IlSchedule() {
+        int i = 0, qk = 0, pv = 0;
+        while (i < N) {
+            if (NEXT && qk < KS) {
+                is_pv[i] = 0, a[i] = qk, b[i] = 0;
+                ++qk, ++i;
+            }
+            if (pv < 2 * MT) {
+                is_pv[i] = 1, a[i] = pv % MT, b[i] = pv / MT;   // a = M-tile, b = 16-key k-step of the half
+                ++pv, ++i;
+            }
+        }
+    }
+};
+
+template <typename T, int DH, int NW, int MODE, int MINW>
+__global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p) {
     typedef AttnCfg<DH, 64> C;
     typedef typename T::elem E;
     typedef typename T::vec8 vec8;
     typedef typename T::vec4 vec4;
-    constexpr int NT = 512;
+    constexpr int NT = 64 * NW;
     constexpr int NPK = C::npk(NT), NPV = C::npv(NT);
     constexpr int BUF_ELEMS = C::K_ELEMS + C::V_ELEMS;
+    constexpr bool ONES = (DH % 32) != 0;   // denominator from the MFMA (row DH of the V^T image = 1.0)
     constexpr int ONES_R = ((DH % 32) & 3) + 4 * ((DH % 32) >> 3);
+    static_assert(!ONES || ((DH % 32) & 4) == 0, "row DH must live in lane half 0");
+    constexpr bool BOUND = DH == 40;        // needs the key norms of the pre-pass
     constexpr float BOUND_T = std::is_same<E, _Float16>::value ? 14.0f : 60.0f;
-    static_assert(NPK == 1 && NPV == 1, "one K piece and one V^T piece per thread");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     auto sK = [&](int buf) { return reinterpret_cast<E*>(smem) + buf * BUF_ELEMS; };
@@ -1209,13 +1235,14 @@ __global__ __launch_bounds__(512, MINW) void ext_attn_il40_kernel(AttnParams p) 
     const int64_t vt_row = vt_row_stride(K, p.Spad);
     const E* vg = reinterpret_cast<const E*>(p.vt) + ((int64_t)(b * H + h) * DH) * vt_row;
 
-    // ---- LDS init: zero everything (pads; the V^T rows 41..63), then the denominator row DH of both V^T images
+    // ---- LDS init: zero everything (pads; the V^T rows past DH), then the denominator row DH of both V^T images
     for (int id = tid; id < 2 * BUF_ELEMS / 8; id += NT) st16(reinterpret_cast<E*>(smem) + id * 8, u32x4{0, 0, 0, 0});
     __syncthreads();
-    for (int id = tid; id < 2 * 64; id += NT) sV(id >> 6)[DH * C::VROW + (id & 63)] = (E)1.f;
+    if constexpr (ONES)
+        for (int id = tid; id < 2 * 64; id += NT) sV(id >> 6)[DH * C::VROW + (id & 63)] = (E)1.f;
 
     // ---- Q fragments
-    const int q_row = qt * 256 + wave * 32 + l31;
+    const int q_row = qt * (32 * NW) + wave * 32 + l31;
     const bool q_ok = q_row < S;
     vec8 qf[C::KS];
     {
@@ -1228,8 +1255,8 @@ __global__ __launch_bounds__(512, MINW) void ext_attn_il40_kernel(AttnParams p) 
     }
     const float c = p.c;
     // score bound (log2 units) over every key this problem sees: |q| max|k| c  (see BOUND in ext_attn_kernel)
-    float s_bound;
-    {
+    float s_bound = 0.f;
+    if constexpr (BOUND) {
         const int ppf = p.Spad / 64;
         const float* part = p.knorm2 + ((int64_t)(bq * H + h) * K + f_lo) * ppf;
         float kn2 = 0.f;
@@ -1245,40 +1272,55 @@ __global__ __launch_bounds__(512, MINW) void ext_attn_il40_kernel(AttnParams p) 
         s_bound = __builtin_sqrtf(q2) * __builtin_sqrtf(kn2) * 1.001f * c;
     }
 
-    // ---- staging: one 16-B piece of K and one of V^T per thread and tile (branch-free, see ext_attn_kernel)
-    u32x4 rk, rv;
-    const int k_id = min(tid, 64 * C::PPR - 1), v_id = min(tid, DH * 8 - 1);
-    const int k_goff = (k_id / C::PPR) * (int)p.ld + (k_id % C::PPR) * 8;
-    const int k_loff = (k_id / C::PPR) * C::KROW + (k_id % C::PPR) * 8;
-    const int v_goff = (v_id >> 3) * (int)vt_row + (v_id & 7) * 8;
-    const int v_loff = (v_id >> 3) * C::VROW + (v_id & 7) * 8;
+    // ---- staging: 16-B pieces of K and of V^T per thread and tile (branch-free, see ext_attn_kernel)
+    u32x4 rk[NPK], rv[NPV];
+    int k_goff[NPK], k_loff[NPK], v_goff[NPV], v_loff[NPV];
+#pragma unroll
+    for (int i = 0; i < NPK; ++i) {
+        const int id = min(tid + NT * i, 64 * C::PPR - 1);
+        k_goff[i] = (id / C::PPR) * (int)p.ld + (id % C::PPR) * 8;
+        k_loff[i] = (id / C::PPR) * C::KROW + (id % C::PPR) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+        const int id = min(tid + NT * i, DH * 8 - 1);
+        v_goff[i] = (id >> 3) * (int)vt_row + (id & 7) * 8;
+        v_loff[i] = (id >> 3) * C::VROW + (id & 7) * 8;
+    }
     const int v_wrap = p.Spad - (tpf - 1) * 64;
     const int64_t k_wrap_off = p.k_fs - (int64_t)(tpf - 1) * 64 * p.ld;
     const E* k_next = kg + f_lo * p.k_fs;
     const E* v_next = vg + (int64_t)f_lo * p.Spad;
     int k_tt = 0, v_tt = 0;
     auto load_k = [&]() {
-        rk = ld16(k_next + k_goff);
+#pragma unroll
+        for (int i = 0; i < NPK; ++i) rk[i] = ld16(k_next + k_goff[i]);
         const bool wrap = k_tt == tpf - 1;
         k_next += wrap ? k_wrap_off : (int64_t)64 * p.ld;
         k_tt = wrap ? 0 : k_tt + 1;
     };
     auto load_v = [&]() {
-        rv = ld16(v_next + v_goff);
+#pragma unroll
+        for (int i = 0; i < NPV; ++i) rv[i] = ld16(v_next + v_goff[i]);
         const bool wrap = v_tt == tpf - 1;
         v_next += wrap ? v_wrap : 64;
         v_tt = wrap ? 0 : v_tt + 1;
     };
     auto write_k = [&](int buf) {
-        if (tid < 64 * C::PPR) st16(sK(buf) + k_loff, rk);
+#pragma unroll
+        for (int i = 0; i < NPK; ++i)
+            if (tid + NT * i < 64 * C::PPR) st16(sK(buf) + k_loff[i], rk[i]);
     };
     auto write_v = [&](int buf) {
-        if (tid < DH * 8) st16(sV(buf) + v_loff, rv);
+#pragma unroll
+        for (int i = 0; i < NPV; ++i)
+            if (tid + NT * i < DH * 8) st16(sV(buf) + v_loff[i], rv[i]);
     };
 
     f32x16 o[C::MT], s[2];
     vec8 pf[2][2];      // P of the two 32-key halves, two 16-key k-steps each
-    float m_run = -INFINITY;   // deferred shift, raw-score units
+    float m_run = -INFINITY;   // BOUND: deferred shift; else the running maximum (raw-score units)
+    float l_run = 0.f;         // !ONES: this lane's share of the denominator
 #pragma unroll
     for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
@@ -1296,16 +1338,29 @@ __global__ __launch_bounds__(512, MINW) void ext_attn_il40_kernel(AttnParams p) 
         constexpr int X = decltype(x_c)::value;
         move = false;
         float alpha = 1.f;
-        if (__any(s_bound - m_run * c > BOUND_T)) {
+        auto half_max = [&]() {
             float mx = s[X][0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[X][r]);
-            mx = max_with_lane_xor32(mx);
-            const bool over = (mx - m_run) * c > BOUND_T;
-            if (__any(over)) {
+            return max_with_lane_xor32(mx);
+        };
+        if constexpr (BOUND) {
+            if (__any(s_bound - m_run * c > BOUND_T)) {
+                const float mx = half_max();
+                const bool over = (mx - m_run) * c > BOUND_T;
+                if (__any(over)) {
+                    move = true;
+                    const float m_new = over ? mx : m_run;
+                    alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);   // exp2(-inf) = 0 on the first half tile (O is 0)
+                    m_run = m_new;
+                }
+            }
+        } else {
+            const float mx = half_max();
+            if (__any(mx > m_run)) {   // rescale only when some query of this wave saw a new maximum
                 move = true;
-                const float m_new = over ? mx : m_run;
-                alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);   // exp2(-inf) = 0 on the first half tile (O is 0)
+                const float m_new = fmaxf(m_run, mx);
+                alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
                 m_run = m_new;
             }
         }
@@ -1320,12 +1375,14 @@ __global__ __launch_bounds__(512, MINW) void ext_attn_il40_kernel(AttnParams p) 
     // one softmax unit: two scores of half X -> P (8 units per half).  Beside MFMAs hipcc emits most of these
     // multiply-adds as two scalar v_fma instead of one v_pk_fma_f32 -- rightly: forcing the packed form (inline asm)
     // measured +8 % (4.30 vs 3.97 ms), the packed f32 VALU delays the MFMAs issued around it.
-    auto sm_unit = [&](auto x_c, int un, f32x2 c2, f32x2 mc2) {
+    auto sm_unit = [&](auto x_c, int un, f32x2 c2, f32x2 mc2, float& lsum) {
         constexpr int X = decltype(x_c)::value;
         const int r = un * 2;
         const f32x2 x = f32x2{s[X][r], s[X][r + 1]} * c2 - mc2;
-        pf[X][r >> 3][r & 7] = (E)__builtin_amdgcn_exp2f(x[0]);
-        pf[X][r >> 3][(r & 7) + 1] = (E)__builtin_amdgcn_exp2f(x[1]);
+        const float p0 = __builtin_amdgcn_exp2f(x[0]), p1 = __builtin_amdgcn_exp2f(x[1]);
+        if constexpr (!ONES) lsum += p0 + p1;
+        pf[X][r >> 3][r & 7] = (E)p0;
+        pf[X][r >> 3][(r & 7) + 1] = (E)p1;
     };
 
     // One phase: the MFMAs of P.V half Hh of the current tile (V^T buffer vbuf) and -- NEXT -- of QK^T half Hh of the
@@ -1334,14 +1391,10 @@ __global__ __launch_bounds__(512, MINW) void ext_attn_il40_kernel(AttnParams p) 
         constexpr int Hh = decltype(h_c)::value;
         constexpr int X = 1 - Hh;
         constexpr bool NEXT = decltype(next_c)::value, SM = decltype(sm_c)::value;
-        constexpr int NM = NEXT ? 7 : 4;
-        // MFMA order: never two MFMAs on the same accumulator next to each other
-        //   NEXT: QK k0, PV(m0,ks0), QK k1, PV(m1,ks0), QK k2, PV(m0,ks1), PV(m1,ks1);  else the four PV
-        constexpr int is_pv[7] = {NEXT ? 0 : 1, 1, NEXT ? 0 : 1, 1, 0, 1, 1};
-        constexpr int idx_a[7] = {0, NEXT ? 0 : 1, NEXT ? 1 : 0, 1, 2, 0, 1};   // PV: M-tile;  QK: k-step
-        constexpr int idx_b[7] = {0, 0, NEXT ? 0 : 1, NEXT ? 0 : 1, 0, 1, 1};   // PV: 16-key k-step of the half
+        constexpr IlSchedule<C::MT, C::KS, NEXT> sch{};
+        constexpr int NM = sch.N;
         bool move = false;
-        float alpha = 1.f;
+        float alpha = 1.f, lsum = 0.f;
         f32x2 c2 = {c, c}, mc2 = {0.f, 0.f};
         if constexpr (SM) {
             alpha = sm_decide(std::integral_constant<int, X>{}, move);
@@ -1351,25 +1404,25 @@ __global__ __launch_bounds__(512, MINW) void ext_attn_il40_kernel(AttnParams p) 
         const E* vbase = sV(vbuf) + l31 * C::VROW + Hh * 32 + 8 * hi;
         const E* kbase = sK(kbuf) + (Hh * 32 + l31) * C::KROW + 8 * hi;
         auto frag = [&](int i) -> vec8 {
-            if (is_pv[i]) return __builtin_bit_cast(vec8, ld16(vbase + idx_a[i] * 32 * C::VROW + 16 * idx_b[i]));
-            return __builtin_bit_cast(vec8, ld16(kbase + 16 * idx_a[i]));
+            if (sch.is_pv[i]) return __builtin_bit_cast(vec8, ld16(vbase + sch.a[i] * 32 * C::VROW + 16 * sch.b[i]));
+            return __builtin_bit_cast(vec8, ld16(kbase + 16 * sch.a[i]));
         };
-        constexpr int PF = 2;   // fragment reads run PF steps ahead of their MFMA (3: 132 VGPRs, one workgroup per CU)
+        constexpr int PF = 2;   // fragment reads run PF steps ahead of their MFMA (3 at Dh = 40: 132 VGPRs, one workgroup per CU)
         vec8 fr[NM];
 #pragma unroll
         for (int i = 0; i < PF && i < NM; ++i) fr[i] = frag(i);
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
             if (i + PF < NM) fr[i + PF] = frag(i + PF);
-            if (is_pv[i]) {
-                o[idx_a[i]] = T::mfma32(fr[i], pf[Hh][idx_b[i]], o[idx_a[i]]);
+            if (sch.is_pv[i]) {
+                o[sch.a[i]] = T::mfma32(fr[i], pf[Hh][sch.b[i]], o[sch.a[i]]);
             } else {
-                s[Hh] = T::mfma32(fr[i], qf[idx_a[i]], idx_a[i] == 0 ? zero : s[Hh]);
+                s[Hh] = T::mfma32(fr[i], qf[sch.a[i]], sch.a[i] == 0 ? zero : s[Hh]);
             }
             if constexpr (SM) {
 #pragma unroll
                 for (int un = (i * 8) / NM; un < ((i + 1) * 8) / NM; ++un)
-                    sm_unit(std::integral_constant<int, X>{}, un, c2, mc2);
+                    sm_unit(std::integral_constant<int, X>{}, un, c2, mc2, lsum);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1377,9 +1430,14 @@ __global__ __launch_bounds__(512, MINW) void ext_attn_il40_kernel(AttnParams p) 
             // P of half X must exist HERE (keeps the register-only softmax from sinking towards its consumer)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(pf[X][ks]));
-            // the shift moved: O (now including this phase's P.V, computed against the old shift) is rescaled before
-            // any P at the new shift is multiplied in
-            if (move) rescale(alpha);
+            // the shift moved: O (now including this phase's P.V, computed against the old shift) -- and the part of
+            // the denominator accumulated so far, all of it at the old shift -- is rescaled before any P at the new
+            // shift is multiplied in / added
+            if (move) {
+                rescale(alpha);
+                if constexpr (!ONES) l_run *= alpha;
+            }
+            if constexpr (!ONES) l_run += lsum;
         }
     };
     typedef std::integral_constant<int, 0> H0;
@@ -1403,11 +1461,13 @@ __global__ __launch_bounds__(512, MINW) void ext_attn_il40_kernel(AttnParams p) 
     }
     {
         bool move;
-        (void)sm_decide(H0{}, move);       // first half tile: sets the shift; O is zero, nothing to rescale
+        (void)sm_decide(H0{}, move);       // first half tile: sets the shift; O and l are zero, nothing to rescale
         const float mc = m_run * c;
         const f32x2 c2 = {c, c}, mc2 = {mc, mc};
+        float lsum = 0.f;
 #pragma unroll
-        for (int un = 0; un < 8; ++un) sm_unit(H0{}, un, c2, mc2);
+        for (int un = 0; un < 8; ++un) sm_unit(H0{}, un, c2, mc2, lsum);
+        if constexpr (!ONES) l_run = lsum;
     }
 
     // All tiles but the last: every phase also runs the QK^T half of the NEXT tile.  The last tile is peeled (no
@@ -1436,7 +1496,11 @@ __global__ __launch_bounds__(512, MINW) void ext_attn_il40_kernel(AttnParams p) 
     }
 
     // ---- epilogue
-    const float l_tot = __shfl(o[C::MT - 1][ONES_R], l31);   // row DH of the V^T image is 1.0: sum of P from the MFMA
+    float l_tot;
+    if constexpr (ONES)
+        l_tot = __shfl(o[C::MT - 1][ONES_R], l31);   // row DH of the V^T image is 1.0: sum of P from the MFMA
+    else
+        l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv_l = 1.0f / l_tot;
     if (split) {
         // split form: unnormalised O, denominator and shift (log2 domain) of this run of frames for attn_merge_kernel
@@ -1478,18 +1542,18 @@ __global__ __launch_bounds__(512, MINW) void ext_attn_il40_kernel(AttnParams p) 
     }
 }
 
-template <typename T, int MODE, int MINW>
-int launch_il40(AttnParams p, hipStream_t st) {
-    typedef AttnCfg<40, 64> C;
+template <typename T, int DH, int NW, int MODE, int MINW>
+int launch_il(AttnParams p, hipStream_t st) {
+    typedef AttnCfg<DH, 64> C;
     constexpr size_t lds = C::lds_bytes(1);
-    auto kern = ext_attn_il40_kernel<T, MODE, MINW>;
+    auto kern = ext_attn_il_kernel<T, DH, NW, MODE, MINW>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-    p.nQT = (p.S + 255) / 256;
+    p.nQT = (p.S + 32 * NW - 1) / (32 * NW);
     const int per_branch = p.Kq * p.nQT * p.H;
     const unsigned grid = (unsigned)(MODE == MODE_ALL ? (2 * p.nseg + (p.part == TF_ATTN_BANK_ONLY ? 0 : 1)) * per_branch
                                                       : per_branch);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, p);
     TF_LAUNCH_CHECK("tf_ext_attn_fwd");
     return 0;
 }
@@ -1582,17 +1646,17 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
 #define TF_TUNE_IL40_MIN_WGS 768
 #endif
 #ifndef TF_TUNE_NO_IL40
-            // half-tile interleaved form (ext_attn_il40_kernel)
+            // half-tile interleaved form (ext_attn_il_kernel)
             const bool il = p.S >= 256 && p.S % 64 == 0 &&
                             (int64_t)3 * p.Kq * ((p.S + 255) / 256) * p.H * p.nseg >= TF_TUNE_IL40_MIN_WGS;
 #else
             const bool il = false;
 #endif
-            return compose([&] { return il    ? launch_il40<T, MODE_ALL, 4>(p, st)
+            return compose([&] { return il    ? launch_il<T, 40, 8, MODE_ALL, 4>(p, st)
                                         : big ? launch_one<T, DH, 1, 8, MODE_ALL, 2, false>(p, st)
                                               : launch_one<T, DH, 1, 4, MODE_ALL, 2, false>(p, st); },
                            [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 3, false>(p, st); },
-                           [&] { return il    ? launch_il40<T, MODE_SOURCE, 4>(p, st)
+                           [&] { return il    ? launch_il<T, 40, 8, MODE_SOURCE, 4>(p, st)
                                         : big ? launch_one<T, DH, 1, 8, MODE_SOURCE, 2, false>(p, st)
                                               : launch_one<T, DH, 1, 4, MODE_SOURCE, 2, false>(p, st); });
         }
@@ -1607,14 +1671,38 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
                        [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st); },
                        [&] { return launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st); });
     } else if constexpr (DH == 80) {
-        return compose([&] { return launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st); },
+#ifndef TF_TUNE_IL80_NW
+#define TF_TUNE_IL80_NW 4
+#endif
+#ifndef TF_TUNE_IL80_MINW
+#define TF_TUNE_IL80_MINW 2
+#endif
+#ifndef TF_TUNE_NO_IL80
+        const bool il = p.S % 64 == 0 && p.S >= 256;   // half-tile interleaved form (ext_attn_il_kernel)
+#else
+        const bool il = false;
+#endif
+        return compose([&] { return il ? launch_il<T, DH, TF_TUNE_IL80_NW, MODE_ALL, TF_TUNE_IL80_MINW>(p, st)
+                                       : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st); },
                        [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st); },
-                       [&] { return launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st); });
+                       [&] { return il ? launch_il<T, DH, TF_TUNE_IL80_NW, MODE_SOURCE, TF_TUNE_IL80_MINW>(p, st)
+                                       : launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st); });
     } else {
         // Dh=160: the dual (shared-softmax) form needs 160 more accumulator registers and measured slower;
         // under injection the ALL form reads the source q and k for every branch instead
-        if (src_only) return launch_one<T, DH, 1, 4, MODE_SOURCE, 1>(p, st);
-        const int rc = launch_one<T, DH, 1, 4, MODE_ALL, 1>(p, st);
+#ifndef TF_TUNE_IL160_MINW
+#define TF_TUNE_IL160_MINW 2
+#endif
+#ifndef TF_TUNE_NO_IL160
+        const bool il = p.S % 64 == 0 && p.S >= 256;   // 8 waves share the 89 KB of tiles: 2 waves per SIMD
+#else
+        const bool il = false;
+#endif
+        if (src_only)
+            return il ? launch_il<T, DH, 8, MODE_SOURCE, TF_TUNE_IL160_MINW>(p, st)
+                      : launch_one<T, DH, 1, 4, MODE_SOURCE, 1>(p, st);
+        const int rc = il ? launch_il<T, DH, 8, MODE_ALL, TF_TUNE_IL160_MINW>(p, st)
+                          : launch_one<T, DH, 1, 4, MODE_ALL, 1>(p, st);
         return rc ? rc : merge();
     }
 }
