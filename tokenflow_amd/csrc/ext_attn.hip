@@ -736,10 +736,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
 static int split_plan(int K, int Kq, int S, int H, int Dh, bool inject, int part, bool allow) {
     if (!allow || part == TF_ATTN_SOURCE_ONLY) return 1;
     const bool dual = inject && S >= 256 && Dh != 160;
-#ifndef TF_TUNE_OCC160
-#define TF_TUNE_OCC160 1
-#endif
-    const int occ = Dh == 40 ? (dual ? 3 : 4) : Dh == 160 ? TF_TUNE_OCC160 : (dual ? 2 : 3);   // waves per SIMD the kernels reach
+    const int occ = Dh == 40 ? (dual ? 3 : 4) : Dh == 160 ? 1 : (dual ? 2 : 3);   // waves per SIMD the kernels reach
     const int64_t wgs = (int64_t)(dual ? 1 : 2) * Kq * ((S + 127) / 128) * H;   // 4-wave workgroups
     const int tpf = (S + 63) / 64;
     if (K * tpf < 16) return 1;   // a bank of a few tiles: the merge launch costs more than it buys (8x8 level)
@@ -1136,18 +1133,18 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Half-tile interleaved variant (fp32 score scaling): Dh = 40 (the cfg2 / cfg3 level-0 form), 80, 160.
+// Half-tile interleaved variant (fp32 score scaling): Dh = 40 (the cfg2 / cfg3 level-0 form) and 80.
 //
 // The plain kernel runs QK^T -> softmax (64 VALU) -> P.V of one 64-key tile back to back: inside a wave the matrix
 // pipe idles during the softmax and the VALU during the MFMAs, and the overlap that independent waves on a SIMD
 // provide stops at ~49 % matrix-pipe utilisation at Dh = 40 -- and does not exist at all where the
-// registers / LDS of the larger head dims leave one or two waves per SIMD (Dh = 160: 89 KB of tiles per workgroup).
+// registers of the larger head dims leave two waves per SIMD.
 // Here ONE query tile per wave is software-pipelined over 32-key half tiles, so that every stretch of the
 // instruction stream has INDEPENDENT matrix and vector work, issued alternately (one MFMA, its share of the softmax,
 // pinned by sched_barrier(0)):
 //     phase 1 of tile t:  O += V0(t) P0(t)  and  S0(t+1) = K0(t+1) Q   (2 MT + KS MFMAs)  ||  P1(t)   = exp2(S1(t) c - m c)
 //     phase 2 of tile t:  O += V1(t) P1(t)  and  S1(t+1) = K1(t+1) Q                       ||  P0(t+1) = exp2(S0(t+1) c - m c)
-// (7 MFMAs per phase at Dh = 40, 11 at 80, 20 at 160, against the same 8 softmax units of 2 fma + 2 exp + 1 cvt.)
+// (7 MFMAs per phase at Dh = 40, 11 at 80, against the same 8 softmax units of 2 fma + 2 exp + 1 cvt.)
 // Same LDS images as the plain kernel, K staged one tile earlier (as in the ping-pong kernel): top of iteration t
 // writes K(t+1) and V(t) from registers loaded an iteration before, one barrier, then the two phases.
 // Online softmax: Dh = 40 uses the score bound (BOUND: a half tile looks at its maximum only when the bound does not
@@ -1643,8 +1640,8 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
         const bool big = p.S >= 256 && (int64_t)3 * p.Kq * ((p.S + 255) / 256) * p.H * p.nseg >= 768;
         if (!p.fold) {   // fp32 score scaling: the default
 #ifndef TF_TUNE_IL40_MIN_WGS
-#define TF_TUNE_IL40_MIN_WGS 768
-#endif
+#define TF_TUNE_IL40_MIN_WGS 256   // one 8-wave workgroup per CU: a W = 8 rank's one-pass level 0 (384 workgroups) runs
+#endif                             // 586 us interleaved against 672 us in the plain 4-wave form (profiles/r03_rank_shard.txt)
 #ifndef TF_TUNE_NO_IL40
             // half-tile interleaved form (ext_attn_il_kernel)
             const bool il = p.S >= 256 && p.S % 64 == 0 &&
@@ -1672,7 +1669,7 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
                        [&] { return launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st); });
     } else if constexpr (DH == 80) {
 #ifndef TF_TUNE_IL80_NW
-#define TF_TUNE_IL80_NW 4
+#define TF_TUNE_IL80_NW 8      // 8 waves share a staged tile (165 VGPRs, 2 waves per SIMD); 4: 180 VGPRs, +1..4 %
 #endif
 #ifndef TF_TUNE_IL80_MINW
 #define TF_TUNE_IL80_MINW 2
@@ -1689,20 +1686,12 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
                                        : launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st); });
     } else {
         // Dh=160: the dual (shared-softmax) form needs 160 more accumulator registers and measured slower;
-        // under injection the ALL form reads the source q and k for every branch instead
-#ifndef TF_TUNE_IL160_MINW
-#define TF_TUNE_IL160_MINW 2
-#endif
-#ifndef TF_TUNE_NO_IL160
-        const bool il = p.S % 64 == 0 && p.S >= 256;   // 8 waves share the 89 KB of tiles: 2 waves per SIMD
-#else
-        const bool il = false;
-#endif
-        if (src_only)
-            return il ? launch_il<T, DH, 8, MODE_SOURCE, TF_TUNE_IL160_MINW>(p, st)
-                      : launch_one<T, DH, 1, 4, MODE_SOURCE, 1>(p, st);
-        const int rc = il ? launch_il<T, DH, 8, MODE_ALL, TF_TUNE_IL160_MINW>(p, st)
-                          : launch_one<T, DH, 1, 4, MODE_ALL, 1>(p, st);
+        // under injection the ALL form reads the source q and k for every branch instead.  The interleaved kernel
+        // was measured here too (8 waves sharing the 89 KB of tiles, 237 VGPRs): 97 vs 92 us at cfg2 level 2 -- at
+        // this head dim every MFMA needs its own 1 KB fragment from LDS, whose read rate (128 B/clk per CU) equals
+        // the matrix pipes' demand, and the level has one wave per SIMD whatever the kernel.
+        if (src_only) return launch_one<T, DH, 1, 4, MODE_SOURCE, 1>(p, st);
+        const int rc = launch_one<T, DH, 1, 4, MODE_ALL, 1>(p, st);
         return rc ? rc : merge();
     }
 }

@@ -6,6 +6,8 @@
 // pivots of the NN search -- 1/||y||_2 of the ROUNDED output row as a side product (what
 // tf_pivot_inv_norm computes from the stored pivots, util.py:67), so the pivots are never re-read.
 // 16/32/64 lanes per row by D, the row lives in registers (D <= 2048); HBM-bound.
+#include <type_traits>
+
 #include "tf_common.h"
 
 namespace {
@@ -94,13 +96,78 @@ __device__ __forceinline__ float row_sum(float x) {
 
 constexpr int LN_MAXP = 4;   // 16-B pieces per lane
 
+// 8 consecutive elements as they come from memory (16 B of a 16-bit type, 32 B of fp32): loads are issued as raw
+// words and converted when the row is processed, so that the NEXT row group's loads are in flight while the current
+// one is reduced and stored
+struct Raw8 {
+    u32x4 a, b;
+};
+struct Raw4 {
+    u32x4 a;
+};
+template <typename T>
+__device__ __forceinline__ void raw_load(const T* p, Raw8& r) {
+    r.a = ld16(p);
+    r.b = ld16(p + 4);
+}
+template <typename T>
+__device__ __forceinline__ void raw_load(const T* p, Raw4& r) {
+    r.a = ld16(p);
+}
+__device__ __forceinline__ void raw_load_dt(const void* base, int dtype, int64_t off, Raw8& r) {
+    if (dtype == TF_F32) {
+        r.a = ld16(reinterpret_cast<const float*>(base) + off);
+        r.b = ld16(reinterpret_cast<const float*>(base) + off + 4);
+    } else {
+        r.a = ld16(reinterpret_cast<const uint16_t*>(base) + off);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void raw_cvt(const Raw8& r, float (&f)[8]) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[i] = __uint_as_float(r.a[i]);
+            f[4 + i] = __uint_as_float(r.b[i]);
+        }
+    } else {
+        typedef T v8 __attribute__((ext_vector_type(8)));
+        const v8 v = __builtin_bit_cast(v8, r.a);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+    }
+}
+template <typename T>
+__device__ __forceinline__ void raw_cvt(const Raw4& r, float (&f)[8]) {
+    typedef T v8 __attribute__((ext_vector_type(8)));
+    const v8 v = __builtin_bit_cast(v8, r.a);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
+__device__ __forceinline__ void raw_cvt_dt(const Raw8& r, int dtype, float dflt, bool have, float (&f)[8]) {
+    if (!have) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = dflt;
+    } else if (dtype == TF_F32) {
+        raw_cvt<float>(r, f);
+    } else if (dtype == TF_BF16) {
+        raw_cvt<__bf16>(r, f);
+    } else {
+        raw_cvt<_Float16>(r, f);
+    }
+}
+
 // LPR lanes per row, 64/LPR rows per wave: a row of D = 320 is 40 pieces -- with a whole wave per row a third of
 // the lanes idle and every row pays three full-wave reductions; 16 lanes per row keep all lanes busy on 4 rows.
 // D <= LPR * 8 * LN_MAXP.
+// A wave walks its row groups with a one-deep software pipeline: the raw loads of the next group (and, once, the
+// norm's weights -- they depend on the piece only) are issued before the current group is reduced, normalised and
+// stored, so the input latency is paid once per wave, not once per row group.
 // ADD: the input row is `x + res` (res of runtime dtype res_dtype), rounded to sum_dtype and written to sum_out
 // first -- `hidden_states = attn_output + hidden_states` followed by the next norm of the block
 // (tokenflow_utils.py:396-403, 409-414) in one pass.
-template <typename TIn, typename TOut, int LPR, bool ADD = false>
+// NP = 16-B pieces per lane the kernel is unrolled for (3 covers D = 320 / 640 / 1280 at 16 / 32 / 64 lanes per row).
+template <typename TIn, typename TOut, int LPR, bool ADD = false, int NP = LN_MAXP>
 __global__ __launch_bounds__(256) void layer_norm_kernel(const TIn* __restrict__ x, const void* __restrict__ gamma,
                                                          const void* __restrict__ beta, TOut* __restrict__ out,
                                                          float* __restrict__ inv_norm, int64_t rows, int D, float eps,
@@ -108,29 +175,65 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const TIn* __restrict__
                                                          int res_dtype = 0, void* __restrict__ sum_out = nullptr,
                                                          int sum_dtype = 0) {
     constexpr int RPW = 64 / LPR;   // rows per wave
+    // gamma / beta as fp32 in LDS, converted once per workgroup: no dtype switch and no global load in the row loop
+    __shared__ __attribute__((aligned(16))) float sw[2][LPR * 8 * NP];
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float g = 1.f, b = 0.f;
+        if (gamma)
+            g = w_dtype == TF_F32    ? reinterpret_cast<const float*>(gamma)[c]
+                : w_dtype == TF_BF16 ? (float)reinterpret_cast<const __bf16*>(gamma)[c]
+                                     : (float)reinterpret_cast<const _Float16*>(gamma)[c];
+        if (beta)
+            b = w_dtype == TF_F32    ? reinterpret_cast<const float*>(beta)[c]
+                : w_dtype == TF_BF16 ? (float)reinterpret_cast<const __bf16*>(beta)[c]
+                                     : (float)reinterpret_cast<const _Float16*>(beta)[c];
+        sw[0][c] = g;
+        sw[1][c] = b;
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int lr = lane % LPR;      // lane within its row
     const int pieces = D >> 3;
     const float inv_d = 1.0f / (float)D;
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
-    for (int64_t r = row0; r < rows; r += (int64_t)gridDim.x * 4 * RPW) {
-        const TIn* xr = x + r * D;
-        float v[LN_MAXP][8];
-        float s = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
+
+    typedef typename std::conditional<sizeof(TIn) == 4, Raw8, Raw4>::type RawIn;
+    RawIn nx[NP];               // next row group: x as loaded
+    Raw8 nr[ADD ? NP : 1];      // ... and res (runtime dtype)
+    auto prefetch = [&](int64_t r) {
 #pragma unroll
-        for (int j = 0; j < LN_MAXP; ++j) {
+        for (int j = 0; j < NP; ++j) {
             const int p = lr + LPR * j;
             if (p < pieces) {
-                ln_load8(xr + p * 8, v[j]);
+                raw_load(x + r * D + p * 8, nx[j]);
+                if constexpr (ADD) raw_load_dt(res, res_dtype, r * D + p * 8, nr[j]);
+            }
+        }
+    };
+    if (row0 < rows) prefetch(row0);
+    for (int64_t r = row0; r < rows; r += stride) {
+        float v[NP][8];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int p = lr + LPR * j;
+            if (p < pieces) {
+                raw_cvt<TIn>(nx[j], v[j]);
                 if constexpr (ADD) {
                     float rr[8];
-                    if (res_dtype == TF_F32) ln_load8(reinterpret_cast<const float*>(res) + r * D + p * 8, rr);
-                    else if (res_dtype == TF_BF16) ln_load8(reinterpret_cast<const __bf16*>(res) + r * D + p * 8, rr);
-                    else ln_load8(reinterpret_cast<const _Float16*>(res) + r * D + p * 8, rr);
+                    raw_cvt_dt(nr[j], res_dtype, 0.f, true, rr);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[j][i] = __fadd_rn(v[j][i], rr[i]);
-                    ln_store_sum(sum_out, sum_dtype, r * D + p * 8, v[j]);
                 }
+            }
+        }
+        if (r + stride < rows) prefetch(r + stride);   // in flight while this group is processed
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int p = lr + LPR * j;
+            if (p < pieces) {
+                if constexpr (ADD) ln_store_sum(sum_out, sum_dtype, r * D + p * 8, v[j]);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) s += v[j][i];
             }
@@ -138,7 +241,7 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const TIn* __restrict__
         const float mean = row_sum<LPR>(s) * inv_d;
         float q = 0.f;
 #pragma unroll
-        for (int j = 0; j < LN_MAXP; ++j)
+        for (int j = 0; j < NP; ++j)
             if (lr + LPR * j < pieces) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -150,14 +253,19 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const TIn* __restrict__
         float ss = 0.f;
         TOut* orow = out + r * D;
 #pragma unroll
-        for (int j = 0; j < LN_MAXP; ++j) {
+        for (int j = 0; j < NP; ++j) {
             const int p = lr + LPR * j;
             if (p < pieces) {
-                float g[8], b[8], y[8];
-                ln_load_w(gamma, w_dtype, p * 8, 1.f, g);
-                ln_load_w(beta, w_dtype, p * 8, 0.f, b);
+                float y[8];
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(&sw[0][p * 8]);
+                const f32x4 g1 = *reinterpret_cast<const f32x4*>(&sw[0][p * 8 + 4]);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(&sw[1][p * 8]);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(&sw[1][p * 8 + 4]);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) y[i] = fmaf((v[j][i] - mean) * rstd, g[i], b[i]);
+                for (int i = 0; i < 4; ++i) {
+                    y[i] = fmaf((v[j][i] - mean) * rstd, g0[i], b0[i]);
+                    y[4 + i] = fmaf((v[j][4 + i] - mean) * rstd, g1[i], b1[i]);
+                }
                 ss += ln_store8(orow + p * 8, y);
             }
         }
@@ -180,15 +288,23 @@ void launch_ln_lpr(const void* x, const void* gamma, const void* beta, void* out
                    int D, float eps, int w_dtype, hipStream_t st, const LnAdd& ad) {
     constexpr int rows_per_wg = 4 * (64 / LPR);
     int64_t blocks = (rows + rows_per_wg - 1) / rows_per_wg;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    if (ad.res)
-        hipLaunchKernelGGL((layer_norm_kernel<TIn, TOut, LPR, true>), dim3((unsigned)blocks), dim3(256), 0, st,
-                           reinterpret_cast<const TIn*>(x), gamma, beta, reinterpret_cast<TOut*>(out), inv_norm, rows, D,
-                           eps, w_dtype, ad.res, ad.res_dtype, ad.sum_out, ad.sum_dtype);
-    else
-        hipLaunchKernelGGL((layer_norm_kernel<TIn, TOut, LPR, false>), dim3((unsigned)blocks), dim3(256), 0, st,
-                           reinterpret_cast<const TIn*>(x), gamma, beta, reinterpret_cast<TOut*>(out), inv_norm, rows, D,
-                           eps, w_dtype, nullptr, 0, nullptr, 0);
+#ifndef TF_TUNE_LN_WGS_PER_CU
+#define TF_TUNE_LN_WGS_PER_CU 8
+#endif
+    if (blocks > 256 * TF_TUNE_LN_WGS_PER_CU) blocks = 256 * TF_TUNE_LN_WGS_PER_CU;   // resident once; the waves loop
+    const bool np3 = (D >> 3) <= 3 * LPR;   // 3 pieces per lane suffice (every SD width): fewer registers
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const TIn*>(x), gamma, beta,
+                           reinterpret_cast<TOut*>(out), inv_norm, rows, D, eps, w_dtype, ad.res, ad.res_dtype,
+                           ad.sum_out, ad.sum_dtype);
+    };
+    if (ad.res) {
+        if (np3) go(layer_norm_kernel<TIn, TOut, LPR, true, 3>);
+        else go(layer_norm_kernel<TIn, TOut, LPR, true, LN_MAXP>);
+    } else {
+        if (np3) go(layer_norm_kernel<TIn, TOut, LPR, false, 3>);
+        else go(layer_norm_kernel<TIn, TOut, LPR, false, LN_MAXP>);
+    }
 }
 
 template <typename TIn, typename TOut>

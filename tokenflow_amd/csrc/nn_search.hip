@@ -16,9 +16,9 @@
 //   pipeline  = global->register prefetch of chunk i+1 issued before the MFMAs of
 //               chunk i, LDS write after them, one barrier per chunk.
 // Two kernels share that epilogue:
-//   nn_search_rb_kernel<T, DK, NCH>  (D = NCH * 16*DK: 320, 640): the wave's 32 target rows live in REGISTERS as
-//               MFMA B fragments for the whole kernel (80 VGPRs per 320 columns), so only the pivot
-//               tiles [32][320] stream through LDS (one ds_read_b128 per MFMA, no target restaging).
+//   nn_search_rb_kernel<T, DK>  (D = 16*DK <= 320): the wave's 32 target rows live in REGISTERS as
+//               MFMA B fragments for the whole kernel (80 VGPRs at D = 320), so only the pivot
+//               tiles [32][D] stream through LDS (one ds_read_b128 per MFMA, no target restaging).
 //   nn_search_kernel<T, WN>     (any D): both operands staged in 64-wide D chunks.
 // Parallelism: grid = (target panels, P keyframes, SPLITS of the pivot range).  With SPLITS > 1
 // every workgroup writes its (best score, index) per target to scratch and nn_finalize_kernel
@@ -284,22 +284,20 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
 }
 
 // ---------------------------------------------------------------------------
-// Register-B variant for D = NCH * 16*DK: one wave = 32 targets whose B fragments stay in registers for the whole
-// kernel (80 VGPRs per 320 columns: D = 320 -> NCH = 1, 3 waves per SIMD; D = 640 -> NCH = 2, 160 VGPRs, 2 waves per
-// SIMD).  Only the pivots stream through LDS, as [32][16*DK] chunk tiles: a pivot tile takes NCH barrier intervals,
-// the accumulator lives across them, the argmax epilogue runs on the last one.
-template <typename T, int DK, int NCH>
-__global__ __launch_bounds__(256, NCH == 1 ? 3 : 2) void nn_search_rb_kernel(
-    const typename T::elem* __restrict__ tgt, const typename T::elem* __restrict__ piv,
-    const float* __restrict__ inv_norm, int32_t* __restrict__ idx_out, NnPartial* __restrict__ part_out, int64_t n_tgt,
-    int S, int kf0, int kf1, int tiles_per_split, NnChunks ch) {
+// Register-B variant for D = 16*DK: one wave = 32 targets whose B fragments stay in registers.
+template <typename T, int DK>
+__global__ __launch_bounds__(256, 3) void nn_search_rb_kernel(const typename T::elem* __restrict__ tgt,
+                                                           const typename T::elem* __restrict__ piv,
+                                                           const float* __restrict__ inv_norm,
+                                                           int32_t* __restrict__ idx_out,
+                                                           NnPartial* __restrict__ part_out, int64_t n_tgt, int S,
+                                                           int kf0, int kf1, int tiles_per_split, NnChunks ch) {
     typedef typename T::elem E;
     typedef typename T::vec8 vec8;
-    constexpr int DC = 16 * DK;              // columns per chunk
-    constexpr int D = DC * NCH;
+    constexpr int D = 16 * DK;
     constexpr int TMR = 32;                  // pivots per tile
-    constexpr int RS = DC + 8;               // LDS row stride (elements): odd number of 16-B slots
-    constexpr int PPR = DC / 8;              // 16-B pieces per chunk row
+    constexpr int RS = D + 8;                // LDS row stride (elements): odd number of 16-B slots
+    constexpr int PPR = D / 8;               // 16-B pieces per row
     constexpr int NP = (TMR * PPR + 255) / 256;
     constexpr int A_ELEMS = TMR * RS;
 
@@ -325,19 +323,16 @@ __global__ __launch_bounds__(256, NCH == 1 ? 3 : 2) void nn_search_rb_kernel(
     const int mt0 = blockIdx.z * tiles_per_split;
     const int n_mt = min(tiles_per_split, n_mt_all - mt0);
 
-    vec8 fb[NCH][DK];
+    vec8 fb[DK];
     {
         const E* tp = tgt + (t_row < t_end ? t_row : t_end - 1) * D + 8 * hi;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int t = 0; t < DK; ++t) fb[c][t] = __builtin_bit_cast(vec8, ld16(tp + c * DC + 16 * t));
+        for (int t = 0; t < DK; ++t) fb[t] = __builtin_bit_cast(vec8, ld16(tp + 16 * t));
     }
 
-    // iteration it = mt * NCH + c: chunk c of pivot tile mt, LDS buffer it & 1
     u32x4 ra[NP];
     float rinv = 0.f;
-    auto stage_load = [&](int mt, int c) {
+    auto stage_load = [&](int mt) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int id = tid + 256 * i;
@@ -345,16 +340,16 @@ __global__ __launch_bounds__(256, NCH == 1 ? 3 : 2) void nn_search_rb_kernel(
                 const int r = id / PPR, pc = id - r * PPR;
                 int row = (mt0 + mt) * TMR + r;
                 row = row < S ? row : S - 1;
-                ra[i] = ld16(pv + (int64_t)row * D + c * DC + pc * 8);
+                ra[i] = ld16(pv + (int64_t)row * D + pc * 8);
             }
         }
-        if (c == 0 && tid < TMR) {
+        if (tid < TMR) {
             int row = (mt0 + mt) * TMR + tid;
             rinv = inv[row < S ? row : S - 1];
         }
     };
-    auto stage_write = [&](int mt, int c) {
-        E* a = sA((mt * NCH + c) & 1);
+    auto stage_write = [&](int mt) {
+        E* a = sA(mt & 1);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int id = tid + 256 * i;
@@ -363,45 +358,35 @@ __global__ __launch_bounds__(256, NCH == 1 ? 3 : 2) void nn_search_rb_kernel(
                 st16(a + r * RS + pc * 8, ra[i]);
             }
         }
-        if (c == 0 && tid < TMR) sInv[(mt & 1) * TMR + tid] = rinv;
+        if (tid < TMR) sInv[(mt & 1) * TMR + tid] = rinv;
     };
 
     float best_v = -INFINITY;
     int best_i = 0;
-    stage_load(0, 0);
-    stage_write(0, 0);
+    stage_load(0);
+    stage_write(0);
     __syncthreads();
-    f32x16 acc;
     for (int mt = 0; mt < n_mt; ++mt) {
+        const bool has_next = mt + 1 < n_mt;
+        if (has_next) stage_load(mt + 1);
+        f32x16 acc;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const bool last_c = c == NCH - 1;
-            const bool has_next = !last_c || mt + 1 < n_mt;
-            const int nmt = last_c ? mt + 1 : mt, nc = last_c ? 0 : c + 1;
-            if (has_next) stage_load(nmt, nc);
-            if (c == 0) {
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const E* arow = sA(mt & 1) + l31 * RS + 8 * hi;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int t = 0; t < DK; ++t) acc = T::mfma32(__builtin_bit_cast(vec8, ld16(arow + 16 * t)), fb[t], acc);
+        const float* si = sInv + (mt & 1) * TMR;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = cd_row(r, hi);
+            const float sc = acc[r] * si[rl];
+            if (sc > best_v) {
+                best_v = sc;
+                best_i = (mt0 + mt) * TMR + rl;
             }
-            const E* arow = sA((mt * NCH + c) & 1) + l31 * RS + 8 * hi;
-#pragma unroll
-            for (int t = 0; t < DK; ++t)
-                acc = T::mfma32(__builtin_bit_cast(vec8, ld16(arow + 16 * t)), fb[c][t], acc);
-            if (last_c) {
-                const float* si = sInv + (mt & 1) * TMR;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rl = cd_row(r, hi);
-                    const float sc = acc[r] * si[rl];
-                    if (sc > best_v) {
-                        best_v = sc;
-                        best_i = (mt0 + mt) * TMR + rl;
-                    }
-                }
-            }
-            if (has_next) stage_write(nmt, nc);
-            __syncthreads();
         }
+        if (has_next) stage_write(mt + 1);
+        __syncthreads();
     }
     const float ov = __shfl_xor(best_v, 32);
     const int oi = __shfl_xor(best_i, 32);
@@ -433,7 +418,7 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const NnPartial* __res
 
 // Launch plan shared by the launchers and tf_nn_search_workspace_bytes.
 struct NnPlan {
-    bool rb;        // register-B kernel (D == 320, 640)
+    bool rb;        // register-B kernel (D == 320)
     bool wide;      // generic kernel with 128-target panels
     int64_t panels;
     int splits, tiles_per_split;
@@ -455,10 +440,7 @@ static int nn_min_wgs(int C) {
 // n_tgt = targets of ONE chunk, C = chunks in the launch (grid.x = C * panels).
 static NnPlan nn_plan(int64_t n_tgt, int S, int D, int P, int C = 1) {
     NnPlan pl;
-#ifndef TF_TUNE_NN_RB640
-#define TF_TUNE_NN_RB640 1
-#endif
-    pl.rb = D == 320 || (TF_TUNE_NN_RB640 && D == 640);
+    pl.rb = D == 320;
     // 128-target panels halve the pivot re-reads; they pay as soon as the grid still fills the GPU after
     // splitting the pivot range (measured at cfg2 level 1, 5120 targets x 2 keyframes: 34.6 vs 39.8 us)
     pl.wide = !pl.rb && ((n_tgt + 127) / 128) * P * C >= 64;
@@ -504,16 +486,16 @@ int launch_nn(const void* tgt, const void* piv, const float* inv_norm, int32_t* 
     return (fin && splits > 1) ? finalize(ws, idx, n_tgt * C * P, splits, st) : 0;
 }
 
-template <typename T, int DK, int NCH>
+template <typename T, int DK>
 int launch_nn_rb(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, NnPartial* ws, int64_t n_tgt,
                  int S, int P, int kf0, int kf1, hipStream_t st, bool fin, int C, int first_single) {
-    constexpr int D = 16 * DK * NCH;
-    const size_t lds = 2 * 32 * (16 * DK + 8) * 2 + 2 * 32 * 4;
+    constexpr int D = 16 * DK;
+    const size_t lds = 2 * 32 * (D + 8) * 2 + 2 * 32 * 4;
     const NnPlan pl = nn_plan(n_tgt, S, D, P, C);
     const int splits = pl.splits, tps = pl.tiles_per_split;
     dim3 grid((unsigned)(pl.panels * C), (unsigned)P, (unsigned)splits);
     const NnChunks ch{n_tgt, (int)pl.panels, first_single};
-    hipLaunchKernelGGL((nn_search_rb_kernel<T, DK, NCH>), grid, dim3(256), lds, st,
+    hipLaunchKernelGGL((nn_search_rb_kernel<T, DK>), grid, dim3(256), lds, st,
                        reinterpret_cast<const typename T::elem*>(tgt), reinterpret_cast<const typename T::elem*>(piv),
                        inv_norm, idx, (splits > 1 || !fin) ? ws : nullptr, n_tgt * C, S, kf0, kf1, tps, ch);
     TF_LAUNCH_CHECK("tf_nn_search");
@@ -524,10 +506,7 @@ template <typename T>
 int dispatch_nn(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, NnPartial* ws, int64_t n_tgt,
                 int S, int D, int P, int kf0, int kf1, hipStream_t st, bool fin, int C = 1, int first_single = 0) {
     const NnPlan pl = nn_plan(n_tgt, S, D, P, C);
-    if (pl.rb && D == 320)
-        return launch_nn_rb<T, 20, 1>(tgt, piv, inv_norm, idx, ws, n_tgt, S, P, kf0, kf1, st, fin, C, first_single);
-    if (pl.rb)
-        return launch_nn_rb<T, 20, 2>(tgt, piv, inv_norm, idx, ws, n_tgt, S, P, kf0, kf1, st, fin, C, first_single);
+    if (pl.rb) return launch_nn_rb<T, 20>(tgt, piv, inv_norm, idx, ws, n_tgt, S, P, kf0, kf1, st, fin, C, first_single);
     // 128-target panels for all but the small target sets (nn_plan), else 64-target panels
     if (pl.wide)
         return launch_nn<T, 2, 64>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin, C, first_single);

@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--link-gbs", type=float, default=50.0, help="assumed achieved rate of one xGMI link, GB/s")
     ap.add_argument("--single-ms", type=float, default=27.9, help="single-GPU step (driver, round 2)")
+    ap.add_argument("--profile", action="store_true", help="cProfile of the host side of 5 steps (first configuration)")
+    ap.add_argument("--only", default="", help="e.g. 'split,auto': run one configuration (split|onepass , auto|heads|bank)")
     args = ap.parse_args()
     cfg = workload.CONFIGS[args.config]
     dev = torch.device("cuda", 0)
@@ -100,6 +102,8 @@ def main():
     w = bench.blend_w(cfg.chunk, dev)
     for split in (True, False):
         for mode in (None, "heads", "bank"):
+            if args.only and args.only != f"{'split' if split else 'onepass'},{mode or 'auto'}":
+                continue
             comm = LocalComm(args.rank, args.world)
             shard = sharded.FrameShard(cfg.K, comm=comm, attn_split=split)
             if mode == "heads" and any(l[2] % args.world for l in cfg.levels):
@@ -109,6 +113,20 @@ def main():
             modes = [mode or shard.auto_mode(l[2], l[0]) for l in cfg.levels]
             print(f"=== rank {args.rank} of {args.world}, {cfg.name}: Kl={shard.Kl}, attention "
                   f"{'split+merge' if split else 'one-pass (bit-exact)'}, exchange per level {modes}", flush=True)
+            if args.profile:
+                import cProfile
+                import pstats
+                for _ in range(3):
+                    bench.run_step(cfg, blocks, shard, False, w, exchange=mode)
+                torch.cuda.synchronize()
+                pr = cProfile.Profile()
+                pr.enable()
+                for _ in range(5):
+                    bench.run_step(cfg, blocks, shard, False, w, exchange=mode)
+                pr.disable()
+                torch.cuda.synchronize()
+                pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+                args.profile = False
             for inj in (False, True):
                 gpu, host = measure(lambda: bench.run_step(cfg, blocks, shard, inj, w, exchange=mode), args.reps, 3)
                 med = statistics.median(gpu)
