@@ -222,6 +222,30 @@ int tf_nn_gather_blend_chunks(const void* tgt, const void* piv, const float* inv
                               int out_dtype, int single_dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * The two calls above with the block's NEXT LayerNorm fused behind them  --  tokenflow_utils.py:329-397 followed by
+ * norm2 (399-403) or, without cross-attention, norm3 (414): `out` is written exactly as by tf_nn_gather_blend[_chunks]
+ * and norm_out = LayerNorm(out) row by row exactly as tf_layer_norm(out) would produce it (bit-identical on both),
+ * but a row never leaves the registers in between: the propagation leaves the residual stream in fp32 (the
+ * reference's promotion, 385-397) and a separate norm re-reads 4 bytes per element to emit 2.
+ * Covers the hook path's types: in_dtype = res_dtype = norm_dtype = the 16-bit model type, resid != NULL,
+ * out_dtype = TF_F32 when two keyframes are blended (always for the chunks form), the model type for P = 1;
+ * D <= 1536 (TF_ERR_DTYPE otherwise: issue the two calls).  gamma, beta: [D] of w_dtype or NULL.  Workspace as the
+ * unfused calls.
+ * ------------------------------------------------------------------------ */
+int tf_nn_gather_blend_norm(const void* tgt, const void* piv, const float* inv_norm, const void* kf_out,
+                            const float* w, const void* resid, void* out, int K, int n, int S, int D, int P, int kf0,
+                            int kf1, int search_dtype, int in_dtype, int res_dtype, int out_dtype, const void* gamma,
+                            const void* beta, float eps, int w_dtype, void* norm_out, int norm_dtype, void* ws,
+                            size_t ws_bytes, void* stream);
+
+int tf_nn_gather_blend_chunks_norm(const void* tgt, const void* piv, const float* inv_norm, const void* kf_out,
+                                   const float* w, const void* resid, void* out, int K, int n, int C, int S, int D,
+                                   int slot0, int first_single, int search_dtype, int in_dtype, int res_dtype,
+                                   int out_dtype, int single_dtype, const void* gamma, const void* beta, float eps,
+                                   int w_dtype, void* norm_out, int norm_dtype, void* ws, size_t ws_bytes,
+                                   void* stream);
+
+/* ------------------------------------------------------------------------
  * Row LayerNorm producer  --  the `norm1` call of TokenFlowBlock.forward
  * (tokenflow_utils.py:313-323; also norm2 / norm3 of the same forward, 399-417)
  * when the block runs in 16 bit:  out[r] = (x[r] - mean) / sqrt(var + eps) * gamma + beta

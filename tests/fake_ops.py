@@ -128,10 +128,21 @@ class FakeOps:
         total = a + b
         return total, self.layer_norm(total, weight, bias, eps, out_dtype)[0]
 
-    def propagate(self, tgt, piv, inv_norm, kf_ids, kf_out, w, n, residual, out_dtype):
-        return self.gather_blend(kf_out, self.nn_search(tgt, piv, inv_norm, kf_ids), w, kf_ids, n, residual, out_dtype)
+    def norm_fusable(self, kf_out, residual, out_dtype, P, norm_dtype):
+        return residual is not None
 
-    def propagate_chunks(self, tgt, piv, inv_norm, kf_out, w, n, n_chunks, slot0, first_single, residual, out_dtype):
+    def _with_norm(self, out, norm):
+        if norm is None:
+            return out
+        weight, bias, eps, ndt = norm
+        return out, self.layer_norm(out, weight, bias, eps, ndt)[0]
+
+    def propagate(self, tgt, piv, inv_norm, kf_ids, kf_out, w, n, residual, out_dtype, norm=None):
+        out = self.gather_blend(kf_out, self.nn_search(tgt, piv, inv_norm, kf_ids), w, kf_ids, n, residual, out_dtype)
+        return self._with_norm(out, norm)
+
+    def propagate_chunks(self, tgt, piv, inv_norm, kf_out, w, n, n_chunks, slot0, first_single, residual, out_dtype,
+                         norm=None):
         """C chunks in one call = C calls of `propagate`, outputs interleaved back to [3, C*n, S, D]; the
         one-keyframe chunk is rounded to the dtype its own call would have produced."""
         S, D = piv.shape[1:]
@@ -147,7 +158,7 @@ class FakeOps:
             o = self.propagate(tgt[j * n * S:(j + 1) * n * S], piv, inv_norm, ids, kf_out, None if single else w,
                                n, r, dt)
             outs.append(o.to(out_dtype).view(3, n, S, D))
-        return torch.stack(outs, dim=1).reshape(3 * n_chunks * n, S, D)
+        return self._with_norm(torch.stack(outs, dim=1).reshape(3 * n_chunks * n, S, D), norm)
 
     def ddim_step(self, x, eps, mu_a, sigma_a, mu_b, sigma_b, out=None):
         res = orc.ddim_step(x, eps, mu_a, sigma_a, mu_b, sigma_b)

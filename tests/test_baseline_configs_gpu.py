@@ -381,6 +381,79 @@ def test_propagate_chunks_equals_per_chunk_calls(K, n, S, D, first, res_dtype):
     assert got.dtype == torch.float32 and torch.equal(got, want)
 
 
+@pytest.mark.parametrize("K,n,S,D", [(3, 2, 1024, 320), (3, 3, 200, 640), (3, 2, 64, 1280), (3, 2, 45, 72)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("affine", [True, False])
+def test_propagate_with_fused_norm_equals_propagate_then_layer_norm(K, n, S, D, dtype, affine):
+    """tf_nn_gather_blend_norm / tf_nn_gather_blend_chunks_norm (the block's next LayerNorm in the gather's epilogue):
+    the result tensor is bit-identical to the unfused call's and the norm bit-identical to tf_layer_norm of that
+    result -- one keyframe (model-dtype result), two keyframes (fp32 result) and the multi-chunk call with and
+    without the one-keyframe chunk."""
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(77 + S)
+    ln = torch.nn.functional.layer_norm
+    piv = ln(torch.randn(K, S, D, generator=g, device="cuda"), (D,)).to(dtype)
+    inv = ops.pivot_inv_norm(piv)
+    kf_out = torch.randn(3 * K, S, D, generator=g, device="cuda").to(dtype)
+    w = orc.blend_weights(n, 1).cuda()
+    gamma = (1 + 0.1 * torch.randn(D, generator=g, device="cuda")).to(dtype) if affine else None
+    beta = (0.1 * torch.randn(D, generator=g, device="cuda")).to(dtype) if affine else None
+    for ids in ([0], [2, 1]):
+        P = len(ids)
+        tgt = ln(torch.randn(n * S, D, generator=g, device="cuda"), (D,)).to(dtype)
+        res = (2 * torch.randn(3 * n, S, D, generator=g, device="cuda")).to(dtype)
+        odt = torch.float32 if P == 2 else dtype
+        assert ops.norm_fusable(kf_out, res, odt, P, dtype)
+        want = ops.propagate(tgt, piv, inv, ids, kf_out, w if P == 2 else None, n, res, odt)
+        want_n, _ = ops.layer_norm(want, gamma, beta, 1e-5, dtype)
+        got, got_n = ops.propagate(tgt, piv, inv, ids, kf_out, w if P == 2 else None, n, res, odt,
+                                   norm=(gamma, beta, 1e-5, dtype))
+        assert got.dtype == odt and got_n.dtype == dtype
+        assert torch.equal(got, want) and torch.equal(got_n, want_n), (ids, float((got_n.float() - want_n.float()).abs().max()))
+    for first in (0, 1):
+        C = K - first
+        tgt = ln(torch.randn(C * n * S, D, generator=g, device="cuda"), (D,)).to(dtype)
+        res = torch.randn(3 * C * n, S, D, generator=g, device="cuda").to(dtype)
+        want = ops.propagate_chunks(tgt, piv, inv, kf_out, w, n, C, first, first == 0, res, torch.float32)
+        want_n, _ = ops.layer_norm(want, gamma, beta, 1e-5, dtype)
+        got, got_n = ops.propagate_chunks(tgt, piv, inv, kf_out, w, n, C, first, first == 0, res, torch.float32,
+                                          norm=(gamma, beta, 1e-5, dtype))
+        assert torch.equal(got, want) and torch.equal(got_n, want_n), first
+    # what the fused form does not cover is refused, not silently computed some other way
+    assert not ops.norm_fusable(kf_out, res.float(), torch.float32, 2, dtype)
+    with pytest.raises(TypeError):
+        ops.propagate_chunks(tgt, piv, inv, kf_out, w, n, C, first, first == 0, res.float(), torch.float32,
+                             norm=(gamma, beta, 1e-5, dtype))
+
+
+def test_hooks_chunk_pass_fused_gather_norm_equals_unfused(monkeypatch):
+    """A propagation pass of a 16-bit block under autocast with the gather+norm fusion (the default) against the same
+    pass with TOKENFLOW_FUSED_GATHER_NORM off: identical block outputs, and the fused call really is the one taken."""
+    ops = _ops()
+    dev = torch.device("cuda")
+    holder, blk = _one_block_pipe(320, 8, dev, torch.bfloat16)
+    K, n, S = 3, 2, 256
+    g = torch.Generator().manual_seed(5)
+    calls = []
+    real = ops.propagate
+    monkeypatch.setattr(hooks.ops, "propagate", lambda *a, **kw: (calls.append(kw.get("norm") is not None), real(*a, **kw))[1])
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        tfu.register_pivotal(holder, True)
+        blk(torch.randn(3 * K, S, 320, generator=g).bfloat16().to(dev), encoder_hidden_states=torch.randn(3 * K, 7, 32, generator=g).bfloat16().to(dev))
+        tfu.register_pivotal(holder, False)
+        x = torch.randn(3 * n, S, 320, generator=g).bfloat16().to(dev)
+        enc = torch.randn(3 * n, 7, 32, generator=g).bfloat16().to(dev)
+        outs = {}
+        for fused in (True, False):
+            monkeypatch.setattr(hooks, "FUSE_GATHER_NORM", fused)
+            for c in (0, 2):
+                tfu.register_batch_idx(holder, c)
+                outs[(fused, c)] = blk(x, encoder_hidden_states=enc)
+    assert calls == [True, True, False, False]
+    for c in (0, 2):
+        assert torch.equal(outs[(True, c)], outs[(False, c)])
+
+
 # ------------------------------------------------------------------------------------------- hook-level pieces
 def _one_block_pipe(D, heads, dev, dtype):
     torch.manual_seed(0)

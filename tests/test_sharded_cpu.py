@@ -40,12 +40,12 @@ class GlooComm:
     def __init__(self):
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
 
-    def allgather(self, local, bank):
+    def allgather(self, local, bank, stream=None):
         assert bank.numel() == self.world * local.numel() and local.is_contiguous() and bank.is_contiguous()
         dist.all_gather_into_tensor(bank.view(-1), local.reshape(-1))
         return bank
 
-    def allgather_rows(self, local, bank, rows):
+    def allgather_rows(self, local, bank, rows, stream=None):
         assert local.is_contiguous() and bank.is_contiguous() and sum(rows) == bank.shape[0]
         assert local.shape[0] == rows[self.rank] and len(rows) == self.world
         parts = list(bank.split(list(rows)))
@@ -59,14 +59,14 @@ class GlooComm:
             r.wait()
         return bank
 
-    def all_to_all_rows(self, send, recv, send_rows=None, recv_rows=None):
+    def all_to_all_rows(self, send, recv, send_rows=None, recv_rows=None, stream=None):
         assert send.is_contiguous() and recv.is_contiguous()
         if send_rows is not None:
             assert sum(send_rows) == send.shape[0] and sum(recv_rows) == recv.shape[0]
         dist.all_to_all_single(recv, send, recv_rows, send_rows)
         return recv
 
-    def sendrecv(self, send, send_peer, recv, recv_peer):
+    def sendrecv(self, send, send_peer, recv, recv_peer, stream=None):
         ts = list(send if send_peer >= 0 else []) + list(recv if recv_peer >= 0 else [])
         if not ts:
             return

@@ -36,6 +36,11 @@ _SIGNATURES = {
     "tf_nn_gather_blend_chunks_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int, _c.c_int]),
     "tf_nn_gather_blend_chunks": (_c.c_int, [_c.c_void_p] * 7 + [_c.c_int] * 12 + [_c.c_void_p, _c.c_size_t,
                                              _c.c_void_p]),
+    "tf_nn_gather_blend_norm": (_c.c_int, [_c.c_void_p] * 7 + [_c.c_int] * 11 + [_c.c_void_p, _c.c_void_p, _c.c_float,
+                                           _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "tf_nn_gather_blend_chunks_norm": (_c.c_int, [_c.c_void_p] * 7 + [_c.c_int] * 12 + [_c.c_void_p, _c.c_void_p,
+                                                  _c.c_float, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p,
+                                                  _c.c_size_t, _c.c_void_p]),
     "tf_layer_norm": (_c.c_int, [_c.c_void_p] * 5 + [_c.c_int64, _c.c_int, _c.c_float] + [_c.c_int] * 3 + [_c.c_void_p]),
     "tf_add_layer_norm": (_c.c_int, [_c.c_void_p] * 6 + [_c.c_int64, _c.c_int, _c.c_float] + [_c.c_int] * 5 + [_c.c_void_p]),
     "tf_ddim_step": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_int64] + [_c.c_float] * 4 + [_c.c_int, _c.c_void_p]),

@@ -66,16 +66,18 @@ class HipComm:
         except Exception:  # noqa: BLE001  (interpreter shutdown)
             pass
 
-    def allgather(self, local: torch.Tensor, bank: torch.Tensor):
-        """bank [world * local.numel()] <- every rank's `local`, in rank order."""
+    def allgather(self, local: torch.Tensor, bank: torch.Tensor, stream: Optional[int] = None):
+        """bank [world * local.numel()] <- every rank's `local`, in rank order.  stream (all methods): the raw
+        hipStream_t to enqueue on; None = the tensors' device's current torch stream."""
         dt = _dev(local, bank)
         if bank.numel() != self.world * local.numel():
             raise ValueError(f"bank has {bank.numel()} elements, expected {self.world} x {local.numel()}")
         _lib.check(_lib.load().tf_allgather_kv(self._h, local.data_ptr(), bank.data_ptr(), local.numel(), dt,
-                                               _stream(local)), "tf_allgather_kv")
+                                               _stream(local) if stream is None else stream), "tf_allgather_kv")
         return bank
 
-    def allgather_rows(self, local: torch.Tensor, bank: torch.Tensor, rows: Sequence[int]):
+    def allgather_rows(self, local: torch.Tensor, bank: torch.Tensor, rows: Sequence[int],
+                       stream: Optional[int] = None):
         """bank [sum(rows), ...] <- rank p's `local` [rows[p], ...] for every p, in rank order (runs of different
         lengths: K keyframes over W ranks with K % W != 0)."""
         dt = _dev(local, bank)
@@ -86,11 +88,11 @@ class HipComm:
             raise ValueError("allgather_rows: row counts do not match the buffers")
         rr = (ctypes.c_int64 * self.world)(*rows)
         _lib.check(_lib.load().tf_allgather_rows(self._h, local.data_ptr(), bank.data_ptr(), rr, row, dt,
-                                                 _stream(local)), "tf_allgather_rows")
+                                                 _stream(local) if stream is None else stream), "tf_allgather_rows")
         return bank
 
     def all_to_all_rows(self, send: torch.Tensor, recv: torch.Tensor, send_rows: Optional[Sequence[int]] = None,
-                        recv_rows: Optional[Sequence[int]] = None):
+                        recv_rows: Optional[Sequence[int]] = None, stream: Optional[int] = None):
         """send [sum(send_rows), ...] -> rows send_rows[p] to peer p; recv [sum(recv_rows), ...] <- recv_rows[p] rows
         from peer p (None = equal parts), like dist.all_to_all_single over dim 0."""
         dt = _dev(send, recv)
@@ -103,10 +105,11 @@ class HipComm:
             raise ValueError("all_to_all_rows: row counts do not match the buffers")
         sr, rr = (ctypes.c_int64 * W)(*send_rows), (ctypes.c_int64 * W)(*recv_rows)
         _lib.check(_lib.load().tf_all_to_all_rows(self._h, send.data_ptr(), recv.data_ptr(), sr, rr, row, dt,
-                                                  _stream(send)), "tf_all_to_all_rows")
+                                                  _stream(send) if stream is None else stream), "tf_all_to_all_rows")
         return recv
 
-    def sendrecv(self, send: Sequence[torch.Tensor], send_peer: int, recv: Sequence[torch.Tensor], recv_peer: int):
+    def sendrecv(self, send: Sequence[torch.Tensor], send_peer: int, recv: Sequence[torch.Tensor], recv_peer: int,
+                 stream: Optional[int] = None):
         """`send` tensors to send_peer while `recv` tensors arrive from recv_peer, one grouped exchange; a peer of -1
         skips that direction."""
         ts = list(send if send_peer >= 0 else []) + list(recv if recv_peer >= 0 else [])
@@ -119,4 +122,4 @@ class HipComm:
         rp = (ctypes.c_void_p * max(nr, 1))(*[t.data_ptr() for t in recv[:nr]])
         re_ = (ctypes.c_int64 * max(nr, 1))(*[t.numel() for t in recv[:nr]])
         _lib.check(_lib.load().tf_sendrecv_pivot(self._h, sp, se, ns, send_peer, rp, re_, nr, recv_peer, dt,
-                                                 _stream(ts[0])), "tf_sendrecv_pivot")
+                                                 _stream(ts[0]) if stream is None else stream), "tf_sendrecv_pivot")

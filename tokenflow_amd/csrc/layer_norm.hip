@@ -8,6 +8,7 @@
 // 16/32/64 lanes per row by D, the row lives in registers (D <= 2048); HBM-bound.
 #include <type_traits>
 
+#include "ln_row.h"
 #include "tf_common.h"
 
 namespace {
@@ -27,34 +28,6 @@ __device__ __forceinline__ void ln_load8(const T* p, float (&f)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
     }
-}
-
-// stores 8 values rounded to T and returns the sum of squares of the ROUNDED values
-template <typename T>
-__device__ __forceinline__ float ln_store8(T* p, const float (&f)[8]) {
-    float ss = 0.f;
-    if constexpr (sizeof(T) == 4) {
-        u32x4 a, b;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a[i] = __float_as_uint(f[i]);
-            b[i] = __float_as_uint(f[4 + i]);
-        }
-        st16(p, a);
-        st16(p + 4, b);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ss = fmaf(f[i], f[i], ss);
-    } else {
-        typedef T v8 __attribute__((ext_vector_type(8)));
-        v8 v;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            v[i] = (T)f[i];
-            ss = fmaf((float)v[i], (float)v[i], ss);
-        }
-        st16(p, __builtin_bit_cast(u32x4, v));
-    }
-    return ss;
 }
 
 __device__ __forceinline__ void ln_load_w(const void* w, int w_dtype, int col, float dflt, float (&f)[8]) {
@@ -84,14 +57,6 @@ __device__ __forceinline__ void ln_store_sum(void* p, int dtype, int64_t off, fl
 #pragma unroll
         for (int i = 0; i < 8; ++i) f[i] = (float)(_Float16)f[i];
     }
-}
-
-// sum over the LPR lanes that share a row (LPR = 16, 32 or 64 consecutive lanes)
-template <int LPR>
-__device__ __forceinline__ float row_sum(float x) {
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) x += __shfl_xor(x, o);
-    return x;
 }
 
 constexpr int LN_MAXP = 4;   // 16-B pieces per lane
@@ -175,21 +140,8 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const TIn* __restrict__
                                                          int res_dtype = 0, void* __restrict__ sum_out = nullptr,
                                                          int sum_dtype = 0) {
     constexpr int RPW = 64 / LPR;   // rows per wave
-    // gamma / beta as fp32 in LDS, converted once per workgroup: no dtype switch and no global load in the row loop
-    __shared__ __attribute__((aligned(16))) float sw[2][LPR * 8 * NP];
-    for (int c = threadIdx.x; c < D; c += 256) {
-        float g = 1.f, b = 0.f;
-        if (gamma)
-            g = w_dtype == TF_F32    ? reinterpret_cast<const float*>(gamma)[c]
-                : w_dtype == TF_BF16 ? (float)reinterpret_cast<const __bf16*>(gamma)[c]
-                                     : (float)reinterpret_cast<const _Float16*>(gamma)[c];
-        if (beta)
-            b = w_dtype == TF_F32    ? reinterpret_cast<const float*>(beta)[c]
-                : w_dtype == TF_BF16 ? (float)reinterpret_cast<const __bf16*>(beta)[c]
-                                     : (float)reinterpret_cast<const _Float16*>(beta)[c];
-        sw[0][c] = g;
-        sw[1][c] = b;
-    }
+    __shared__ __attribute__((aligned(16))) float sw[2][LPR * 8 * NP];   // gamma / beta as fp32 (ln_row.h)
+    ln_stage_weights<256>(sw[0], sw[1], gamma, beta, w_dtype, D);
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int lr = lane % LPR;      // lane within its row
@@ -228,49 +180,16 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const TIn* __restrict__
             }
         }
         if (r + stride < rows) prefetch(r + stride);   // in flight while this group is processed
-        float s = 0.f;
+        if constexpr (ADD) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int p = lr + LPR * j;
-            if (p < pieces) {
-                if constexpr (ADD) ln_store_sum(sum_out, sum_dtype, r * D + p * 8, v[j]);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) s += v[j][i];
+            for (int j = 0; j < NP; ++j) {
+                const int p = lr + LPR * j;
+                if (p < pieces) ln_store_sum(sum_out, sum_dtype, r * D + p * 8, v[j]);
             }
         }
-        const float mean = row_sum<LPR>(s) * inv_d;
-        float q = 0.f;
-#pragma unroll
-        for (int j = 0; j < NP; ++j)
-            if (lr + LPR * j < pieces) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float c = v[j][i] - mean;
-                    q = fmaf(c, c, q);
-                }
-            }
-        const float rstd = 1.0f / __builtin_sqrtf(row_sum<LPR>(q) * inv_d + eps);   // biased variance, as torch
-        float ss = 0.f;
-        TOut* orow = out + r * D;
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int p = lr + LPR * j;
-            if (p < pieces) {
-                float y[8];
-                const f32x4 g0 = *reinterpret_cast<const f32x4*>(&sw[0][p * 8]);
-                const f32x4 g1 = *reinterpret_cast<const f32x4*>(&sw[0][p * 8 + 4]);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(&sw[1][p * 8]);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(&sw[1][p * 8 + 4]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    y[i] = fmaf((v[j][i] - mean) * rstd, g0[i], b0[i]);
-                    y[4 + i] = fmaf((v[j][4 + i] - mean) * rstd, g1[i], b1[i]);
-                }
-                ss += ln_store8(orow + p * 8, y);
-            }
-        }
+        float ss = ln_row_finish<LPR, NP, TOut>(v, lr, pieces, inv_d, eps, sw[0], sw[1], out + r * D);
         if (inv_norm != nullptr) {
-            ss = row_sum<LPR>(ss);
+            ss = ln_row_sum<LPR>(ss);
             if (lr == 0) inv_norm[r] = 1.0f / __builtin_sqrtf(ss);
         }
     }

@@ -368,6 +368,8 @@ def _fused_norm_dtype(mod: torch.nn.Module, x: torch.Tensor, in_dtype=None):
 # the reference's Linear sees (pinned by tests/test_fullsize_gpu.py::test_fused_layer_norm_is_the_autocast_value);
 # "norm1" = only norm1; "none" = always the modules.
 FUSE_NORMS = os.environ.get("TOKENFLOW_FUSED_NORMS", "all")
+# TOKENFLOW_FUSED_GATHER_NORM=0: keep the propagation's gather and the norm behind it as two launches
+FUSE_GATHER_NORM = os.environ.get("TOKENFLOW_FUSED_GATHER_NORM", "1") not in ("", "0")
 
 
 def _block_norm(mod: torch.nn.Module, x: torch.Tensor, want_inv_norm: bool = False, which: str = "norm1"):
@@ -431,6 +433,7 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
             norm_inv = None
             gate_msa = None
             pending = None          # a residual branch output not yet added to hidden_states (see _add_norm)
+            prenorm = None          # (which, tensor): the next norm, already produced by the propagation's gather
             if self.use_ada_layer_norm:
                 norm_hidden_states = self.norm1(hidden_states, timestep)
             elif self.use_ada_layer_norm_zero:
@@ -496,12 +499,29 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
                 piv, inv = self._tf_pivots, self._tf_pivot_inv_norm
                 if kf_base:      # gated copy holds keyframes kf_base.. only: search the same window of the pivots
                     piv, inv = piv[kf_base:kf_base + K], inv[kf_base:kf_base + K]
+                # the norm that consumes this pass's residual stream next (norm2 in front of the cross-attention, else
+                # norm3 in front of the feed-forward) rides in the gather's epilogue when it is a plain LayerNorm: the
+                # fp32 stream is written once and not re-read by a norm launch (row f1/f2 of SURVEY.md section 8)
+                nxt = None
+                if self.attn2 is not None:
+                    nxt = None if self.use_ada_layer_norm else ("norm2", self.norm2)
+                elif not self.use_ada_layer_norm_zero:
+                    nxt = ("norm3", self.norm3)
+                fuse = None
+                if nxt is not None and (FUSE_NORMS == "all" or FUSE_NORMS == nxt[0]) and FUSE_GATHER_NORM:
+                    ndt = _fused_norm_dtype(nxt[1], resid, out_dtype)
+                    if ndt is not None and ops.norm_fusable(kf, resid, out_dtype, 2 if two else 1, ndt):
+                        fuse = (nxt[1].weight, nxt[1].bias, nxt[1].eps, ndt)
                 if n_chunks == 1:
                     ids = [c0 - kf_base] if c0 == 0 else [c0 - kf_base, c0 - 1 - kf_base]
-                    hidden_states = ops.propagate(tgt, piv, inv, ids, kf, w, n, resid, out_dtype)
+                    res = ops.propagate(tgt, piv, inv, ids, kf, w, n, resid, out_dtype, norm=fuse)
                 else:
-                    hidden_states = ops.propagate_chunks(tgt, piv, inv, kf, w, n, n_chunks, c0 - kf_base, c0 == 0,
-                                                         resid, out_dtype)
+                    res = ops.propagate_chunks(tgt, piv, inv, kf, w, n, n_chunks, c0 - kf_base, c0 == 0, resid,
+                                               out_dtype, norm=fuse)
+                if fuse is not None:
+                    hidden_states, prenorm = res[0], (nxt[0], res[1])
+                else:
+                    hidden_states = res
 
             if self.attn2 is not None:
                 if self.use_ada_layer_norm:
@@ -511,6 +531,8 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
                 elif pending is not None:
                     hidden_states, norm_hidden_states = _add_norm(self.norm2, pending, hidden_states, "norm2")
                     pending = None
+                elif prenorm is not None and prenorm[0] == "norm2":
+                    norm_hidden_states = prenorm[1]
                 else:
                     norm_hidden_states = _block_norm(self.norm2, hidden_states, which="norm2")[0]
                 pending = self.attn2(norm_hidden_states, encoder_hidden_states=encoder_hidden_states,
@@ -524,6 +546,8 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
             elif pending is not None:
                 hidden_states, norm_hidden_states = _add_norm(self.norm3, pending, hidden_states, "norm3")
                 pending = None
+            elif prenorm is not None and prenorm[0] == "norm3":
+                norm_hidden_states = prenorm[1]
             else:
                 norm_hidden_states = _block_norm(self.norm3, hidden_states, which="norm3")[0]
             ff_output = self.ff(norm_hidden_states)

@@ -329,11 +329,40 @@ def add_layer_norm(a: torch.Tensor, b: torch.Tensor, weight: Optional[torch.Tens
     return total, out
 
 
+def norm_fusable(kf_out: torch.Tensor, residual: Optional[torch.Tensor], out_dtype: torch.dtype, P: int,
+                 norm_dtype: torch.dtype) -> bool:
+    """Can `propagate` / `propagate_chunks` carry the block's next LayerNorm (their `norm=` argument)?  The fused
+    form covers the hook path's types: a 16-bit cached attention output, a residual and a norm output of that same
+    type, the result in fp32 (two keyframes blended) or that type (one keyframe)."""
+    dt = kf_out.dtype
+    return (dt in (torch.bfloat16, torch.float16) and residual is not None and residual.dtype == dt
+            and norm_dtype == dt and out_dtype == (torch.float32 if P == 2 else dt) and kf_out.shape[-1] <= 1536)
+
+
+def _norm_args(norm, like: torch.Tensor, shape):
+    """(gamma ptr, beta ptr, eps, w dtype code, norm_out tensor, norm dtype code) of a `norm=(weight, bias, eps,
+    dtype)` argument."""
+    weight, bias, eps, ndt = norm
+    if weight is not None and bias is not None and weight.dtype != bias.dtype:
+        bias = bias.to(weight.dtype)
+    wt = weight if weight is not None else bias
+    if wt is not None and wt.dtype not in _DT:
+        raise TypeError(f"propagate: norm weight dtype {wt.dtype}")
+    weight = weight.contiguous() if weight is not None else None
+    bias = bias.contiguous() if bias is not None else None
+    nout = torch.empty(shape, dtype=ndt, device=like.device)
+    return (weight.data_ptr() if weight is not None else 0, bias.data_ptr() if bias is not None else 0, float(eps),
+            _DT[wt.dtype] if wt is not None else 0, nout, _DT[ndt], (weight, bias))
+
+
 def propagate(tgt: torch.Tensor, piv: torch.Tensor, inv_norm: torch.Tensor, kf_ids: Sequence[int],
               kf_out: torch.Tensor, w: Optional[torch.Tensor], n: int, residual: Optional[torch.Tensor],
-              out_dtype: torch.dtype) -> torch.Tensor:
+              out_dtype: torch.dtype, norm=None):
     """nn_search + gather_blend of one chunk in one call (tokenflow_utils.py:329-397): same arguments, same
-    results bit for bit, one launch less (the gather merges the search's per-split candidates itself)."""
+    results bit for bit, one launch less (the gather merges the search's per-split candidates itself).
+    norm = (weight, bias, eps, dtype) of the block's next LayerNorm (see `norm_fusable`): returns
+    (result, LayerNorm(result) in `dtype`) from one gather launch -- tf_nn_gather_blend_norm, both bit-identical to
+    the separate calls."""
     dev = _need_gpu(tgt, piv, inv_norm, kf_out, w, residual)
     lib = _lib.load()
     tgt, piv, kf_out = tgt.contiguous(), piv.contiguous(), kf_out.contiguous()
@@ -347,6 +376,16 @@ def propagate(tgt: torch.Tensor, piv: torch.Tensor, inv_norm: torch.Tensor, kf_i
         residual = residual.contiguous()
     out = torch.empty(3 * n, S, D, dtype=out_dtype, device=kf_out.device)
     ws = _workspace(lib.tf_nn_gather_blend_workspace_bytes(n_tgt, S, D, P), tgt.device, "nn")
+    if norm is not None:
+        if not norm_fusable(kf_out, residual, out_dtype, P, norm[3]):
+            raise TypeError("propagate: these dtypes have no fused-norm form (ops.norm_fusable)")
+        g, b, eps, wdt, nout, ndt, _keep = _norm_args(norm, kf_out, (3 * n, S, D))
+        _launch(dev, "tf_nn_gather_blend_norm", lib.tf_nn_gather_blend_norm, tgt.data_ptr(), piv.data_ptr(),
+                inv_norm.data_ptr(), kf_out.data_ptr(), w.data_ptr() if w is not None else 0, residual.data_ptr(),
+                out.data_ptr(), K, n, S, D, P, int(kf_ids[0]), int(kf_ids[1]) if P == 2 else 0, _DT[tgt.dtype],
+                _DT[kf_out.dtype], _DT[residual.dtype], _DT[out_dtype], g, b, eps, wdt, nout.data_ptr(), ndt,
+                ws.data_ptr(), ws.numel())
+        return out, nout
     _launch(dev, "tf_nn_gather_blend", lib.tf_nn_gather_blend, tgt.data_ptr(), piv.data_ptr(), inv_norm.data_ptr(),
             kf_out.data_ptr(), w.data_ptr() if w is not None else 0,
             residual.data_ptr() if residual is not None else 0, out.data_ptr(),
@@ -357,7 +396,7 @@ def propagate(tgt: torch.Tensor, piv: torch.Tensor, inv_norm: torch.Tensor, kf_i
 
 def propagate_chunks(tgt: torch.Tensor, piv: torch.Tensor, inv_norm: torch.Tensor, kf_out: torch.Tensor,
                      w: torch.Tensor, n: int, n_chunks: int, slot0: int, first_single: bool,
-                     residual: Optional[torch.Tensor], out_dtype: torch.dtype) -> torch.Tensor:
+                     residual: Optional[torch.Tensor], out_dtype: torch.dtype, norm=None):
     """`propagate` for a run of `n_chunks` consecutive chunks of n frames in one call (tf_nn_gather_blend_chunks):
     tgt [n_chunks*n*S, D] chunk-major, residual / result [3*n_chunks*n, S, D]; chunk j matches keyframe slots
     slot0 + j and slot0 + j - 1 of piv / inv_norm / kf_out; first_single: chunk 0 of the run is chunk 0 of the
@@ -369,7 +408,8 @@ def propagate_chunks(tgt: torch.Tensor, piv: torch.Tensor, inv_norm: torch.Tenso
     C = int(n_chunks)
     if C == 1:
         ids = [slot0] if first_single else [slot0, slot0 - 1]
-        return propagate(tgt, piv, inv_norm, ids, kf_out, None if first_single else w, n, residual, out_dtype)
+        return propagate(tgt, piv, inv_norm, ids, kf_out, None if first_single else w, n, residual, out_dtype,
+                         norm=norm)
     if (tgt.dtype != piv.dtype or tgt.shape != (C * n * S, D) or kf_out.shape != (3 * K, S, D) or w is None
             or slot0 + C > K or slot0 < (0 if first_single else 1)):
         raise ValueError("propagate_chunks: bad arguments")
@@ -379,6 +419,16 @@ def propagate_chunks(tgt: torch.Tensor, piv: torch.Tensor, inv_norm: torch.Tenso
     single_dtype = kf_out.dtype if residual is None else torch.promote_types(kf_out.dtype, residual.dtype)
     out = torch.empty(3 * C * n, S, D, dtype=out_dtype, device=kf_out.device)
     ws = _workspace(lib.tf_nn_gather_blend_chunks_workspace_bytes(n * S, S, D, C), tgt.device, "nn")
+    if norm is not None:
+        if not norm_fusable(kf_out, residual, out_dtype, 2, norm[3]):
+            raise TypeError("propagate_chunks: these dtypes have no fused-norm form (ops.norm_fusable)")
+        g, b, eps, wdt, nout, ndt, _keep = _norm_args(norm, kf_out, (3 * C * n, S, D))
+        _launch(dev, "tf_nn_gather_blend_chunks_norm", lib.tf_nn_gather_blend_chunks_norm, tgt.data_ptr(),
+                piv.data_ptr(), inv_norm.data_ptr(), kf_out.data_ptr(), w.data_ptr(), residual.data_ptr(),
+                out.data_ptr(), K, n, C, S, D, int(slot0), 1 if first_single else 0, _DT[tgt.dtype], _DT[kf_out.dtype],
+                _DT[residual.dtype], _DT[out_dtype], _DT[single_dtype], g, b, eps, wdt, nout.data_ptr(), ndt,
+                ws.data_ptr(), ws.numel())
+        return out, nout
     _launch(dev, "tf_nn_gather_blend_chunks", lib.tf_nn_gather_blend_chunks, tgt.data_ptr(), piv.data_ptr(),
             inv_norm.data_ptr(), kf_out.data_ptr(), w.data_ptr(), residual.data_ptr() if residual is not None else 0,
             out.data_ptr(), K, n, C, S, D, int(slot0), 1 if first_single else 0, _DT[tgt.dtype], _DT[kf_out.dtype],

@@ -61,11 +61,13 @@ class _StreamWork:
     """Completion handle of exchanges issued on the side stream: wait() orders the CURRENT stream behind them
     (no host blocking -- the semantics of a c10d work object on the NCCL backend)."""
 
-    def __init__(self, stream):
-        self.stream = stream
+    def __init__(self, stream, device):
+        self.stream, self.device = stream, device
 
     def wait(self):
-        torch.cuda.current_stream().wait_stream(self.stream)
+        # current_stream(device): the device-less form resolves the device through torch.cuda.is_available(),
+        # ~30 us per call on this stack -- it was two thirds of a rank's host time per block
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return True
 
 
@@ -126,28 +128,29 @@ class FrameShard:
         return t
 
     def _side(self, tensors, fn):
-        """HipComm path: run `fn` (RCCL calls through the C ABI, asynchronous on the current stream) on the exchange
-        stream, ordered after everything already enqueued on the compute stream; returns the handle to wait on."""
+        """HipComm path: run `fn(stream)` (RCCL calls through the C ABI, asynchronous on the stream they are handed)
+        on the exchange stream, ordered after everything already enqueued on the compute stream; returns the handle
+        to wait on.  No stream context manager and no device-less torch.cuda query on this path: both cost tens of
+        microseconds of host time per call, several times per block."""
         if not tensors[0].is_cuda:             # host tensors (the CPU tests' stand-in comm): no streams to order
-            fn()
+            fn(None)
             return _Done()
-        cur = torch.cuda.current_stream()
+        dev = tensors[0].device
+        cur = torch.cuda.current_stream(dev)
         if getattr(self, "_cs", None) is None:
-            self._cs = torch.cuda.Stream()
+            self._cs = torch.cuda.Stream(device=dev)
         self._cs.wait_stream(cur)
-        with torch.cuda.stream(self._cs):
-            fn()
-        if not torch.cuda.is_current_stream_capturing():
-            for t in tensors:
-                t.record_stream(self._cs)      # allocator: not reusable before the exchange stream is done with it
-        return _StreamWork(self._cs)
+        fn(self._cs.cuda_stream)
+        for t in tensors:
+            t.record_stream(self._cs)          # allocator: not reusable before the exchange stream is done with it
+        return _StreamWork(self._cs, dev)
 
     def _a2a(self, recv: torch.Tensor, send: torch.Tensor, out_rows=None, in_rows=None, async_op: bool = False):
         """Row all-to-all over dim 0: out_rows[p] rows arrive from peer p, in_rows[p] rows go to peer p (None = equal)."""
         comm = getattr(self, "comm", None)
         if comm is None:
             return _all_to_all(recv, send, self.group, out_rows, in_rows, async_op=async_op)
-        work = self._side([recv, send], lambda: comm.all_to_all_rows(send, recv, in_rows, out_rows))
+        work = self._side([recv, send], lambda st: comm.all_to_all_rows(send, recv, in_rows, out_rows, stream=st))
         if async_op:
             return work
         work.wait()
@@ -187,7 +190,7 @@ class FrameShard:
                 else:
                     dist.all_gather_into_tensor(recv, send, group=self.group)
             else:
-                self._side([recv, send], lambda: comm.allgather(send, recv)).wait()
+                self._side([recv, send], lambda st: comm.allgather(send, recv, stream=st)).wait()
         elif comm is None:       # one grouped point-to-point exchange: my rows to every peer, theirs into place
             staged = send.is_cuda and dist.get_backend(self.group) == "gloo"
             src = send.cpu() if staged else send
@@ -207,7 +210,7 @@ class FrameShard:
             if staged:
                 recv.copy_(dst)
         else:
-            self._side([recv, send], lambda: comm.allgather_rows(send, recv, self.counts)).wait()
+            self._side([recv, send], lambda st: comm.allgather_rows(send, recv, self.counts, stream=st)).wait()
         rp = recv.view(K, ns, S, D).permute(1, 0, 2, 3)        # [ns, K, S, D] views: frame stride ns*S*D
         return (rp[0:1], rp[1:4]) if inject else (rp[0:3], rp[3:6])
 
@@ -360,10 +363,10 @@ class FrameShard:
                 return []
             send_tensors = [t.contiguous() for t in send_tensors]
 
-            def go():       # one grouped call per element type (the C entry point takes one dtype per call)
+            def go(st):     # one grouped call per element type (the C entry point takes one dtype per call)
                 for dt in dict.fromkeys(t.dtype for t in list(send_tensors) + list(recv_tensors)):
                     comm.sendrecv([t for t in send_tensors if t.dtype == dt], to,
-                                  [t for t in recv_tensors if t.dtype == dt], frm)
+                                  [t for t in recv_tensors if t.dtype == dt], frm, stream=st)
             return [self._side(list(send_tensors) + list(recv_tensors), go)]
         opsl = []
         if self.rank + 1 < self.world:

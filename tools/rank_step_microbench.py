@@ -28,37 +28,51 @@ from tokenflow_amd import sharded, workload  # noqa: E402
 
 
 class LocalComm:
-    """HipComm's interface; every exchange is a same-size device copy on the calling stream."""
+    """HipComm's interface; every exchange is a same-size device-to-device hipMemcpyAsync on the stream it is handed
+    (one foreign call per message, like the RCCL calls it stands for)."""
 
     def __init__(self, rank, world):
+        import ctypes
         self.rank, self.world = rank, world
         self.bytes = 0
+        self._hip = ctypes.CDLL("libamdhip64.so")
+        self._hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                             ctypes.c_void_p]
 
-    def allgather(self, local, bank):
-        bank.view(self.world, -1).copy_(local.reshape(1, -1).expand(self.world, -1))
-        self.bytes += local.numel() * local.element_size() * (self.world - 1)
+    def _copy(self, dst, src, nbytes, stream):
+        if stream is None:
+            stream = torch.cuda.current_stream(dst.device).cuda_stream
+        rc = self._hip.hipMemcpyAsync(dst.data_ptr(), src.data_ptr(), nbytes, 3, stream)   # 3 = device to device
+        assert rc == 0, rc
+
+    def allgather(self, local, bank, stream=None):
+        nb = local.numel() * local.element_size()
+        for p in range(self.world):
+            self._hip.hipMemcpyAsync(bank.data_ptr() + p * nb, local.data_ptr(), nb, 3,
+                                     stream if stream is not None else torch.cuda.current_stream(bank.device).cuda_stream)
+        self.bytes += nb * (self.world - 1)
         return bank
 
-    def allgather_rows(self, local, bank, rows):
+    def allgather_rows(self, local, bank, rows, stream=None):
+        rb = bank[0].numel() * bank.element_size()
+        st = stream if stream is not None else torch.cuda.current_stream(bank.device).cuda_stream
         off = 0
         for p, r in enumerate(rows):
-            bank[off:off + r].copy_(local[:1].expand(r, -1) if r != local.shape[0] else local)
+            self._hip.hipMemcpyAsync(bank.data_ptr() + off * rb, local.data_ptr(), min(r, local.shape[0]) * rb, 3, st)
             off += r
         self.bytes += local.numel() * local.element_size() * (self.world - 1)
         return bank
 
-    def all_to_all_rows(self, send, recv, send_rows=None, recv_rows=None):
-        n = min(send.numel(), recv.numel())
-        recv.view(-1)[:n].copy_(send.view(-1)[:n])
-        if recv.numel() > n:
-            recv.view(-1)[n:].copy_(send.view(-1)[:recv.numel() - n])
+    def all_to_all_rows(self, send, recv, send_rows=None, recv_rows=None, stream=None):
+        n = min(send.numel(), recv.numel()) * send.element_size()
+        self._copy(recv, send, n, stream)
         self.bytes += send.numel() * send.element_size() * (self.world - 1) // self.world
         return recv
 
-    def sendrecv(self, send, send_peer, recv, recv_peer):
+    def sendrecv(self, send, send_peer, recv, recv_peer, stream=None):
         if recv_peer >= 0:
             for s, r in zip(send, recv):
-                r.copy_(s)
+                self._copy(r, s, r.numel() * r.element_size(), stream)
         if send_peer >= 0:
             self.bytes += sum(t.numel() * t.element_size() for t in send)
 
