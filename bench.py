@@ -101,7 +101,11 @@ class Block:
             return torch.randn(*shape, generator=gen, device=dev, dtype=torch.float32).to(bf)
         self.q, self.k, self.v = rnd(3 * Kl, S, D), rnd(3 * Kl, S, D), rnd(3 * Kl, S, D)
         ln = torch.nn.functional.layer_norm
-        self.pivots = ln(torch.randn(Kl, S, D, generator=gen, device=dev), (D,)).to(bf)
+        # N > 1: the propagation state of the block lives in halo-extended buffers (slot 0 = the left neighbour's last
+        # keyframe); the pivots sit in slots 1.. from the start, as the block's norm1 would leave them there
+        self.ext = shard.ext_alloc(S, D, bf, dev)
+        self.pivots = self.ext[0][1 if shard.world > 1 else 0:]
+        self.pivots.copy_(ln(torch.randn(Kl, S, D, generator=gen, device=dev), (D,)).to(bf))
         # video-like targets: permuted pivot rows + noise; residual ~ N(0,1).
         # All local chunks in one tensor, chunk-major: tgt [Kl*n*S, D], res [3, Kl*n, S, D]
         tgt, self.perm = [], []
@@ -131,6 +135,13 @@ def run_step(cfg, blocks, shard, inject_on, w, events=None, exchange=None, per_c
         if shard.world == 1:
             kf_out = ops.ext_attn(blk.q, blk.k, blk.v, blk.h, scale, inj)
             halo = None
+        elif two_pass:
+            # N > 1, the reference's own call order (run_tokenflow_pnp.py:222-231): ONE pivotal UNet pass over all 16
+            # blocks, then the chunk passes.  In place: inverse norms and attention output go straight into the block's
+            # halo-extended buffers, ONE grouped neighbour exchange per block (pivots, inverse norms, attention output of
+            # the last local keyframe), which has the rest of the pivotal pass to arrive.
+            ops.pivot_inv_norm(blk.pivots, out=blk.ext[1][1:])
+            pending.append((blk, shard.pivotal_block(blk.q, blk.k, blk.v, blk.h, scale, inj, blk.ext, mode=exchange)))
         else:
             # the pivots' halo (features + inverse norms of the last local keyframe -> rank r+1) does not depend on
             # the attention: issued first, it travels under it
@@ -140,10 +151,6 @@ def run_step(cfg, blocks, shard, inject_on, w, events=None, exchange=None, per_c
             e1.record()
             events.append((e0, e1, inj))
         if two_pass:
-            # N > 1: the reference's own call order (run_tokenflow_pnp.py:222-231) -- ONE pivotal UNet pass over all 16
-            # blocks, then the chunk passes.  The attention-output halo of every block is sent as soon as it exists and
-            # has the rest of the pivotal pass to arrive; nothing waits for the wire until the propagation reads it.
-            pending.append((blk, shard.halo_finish(halo, kf_out, wait=False)))
             continue
         if per_chunk or shard.world == 1:
             if halo is None:

@@ -96,8 +96,9 @@ class FakeOps:
         for b, d in enumerate(dsts):
             d.view(Kl, S, W, hd).copy_(recv[:, :, b].permute(1, 2, 0, 3))
 
-    def pivot_inv_norm(self, piv):
-        return 1.0 / self._r(piv).norm(dim=-1)
+    def pivot_inv_norm(self, piv, out=None):
+        res = 1.0 / self._r(piv).norm(dim=-1)
+        return res if out is None else out.copy_(res)
 
     def nn_search(self, tgt, piv, inv_norm, kf_ids):
         self.calls.append(("nn_search", tuple(tgt.shape), tuple(kf_ids)))

@@ -87,6 +87,7 @@ def _worker(rank, world, port, K, n, S, h, d, inject, mode, ret, use_comm=False)
         sharded.ops = fake
         q, k, v, piv, kf_out, tgt, res = _data(K, n, S, h, d)
         D = h * d
+        h_ = h
         # ---- single-process reference (same fake ops, full data)
         full_attn = fake.ext_attn(q, k, v, h, d ** -0.5, inject)
         inv = fake.pivot_inv_norm(piv)
@@ -123,6 +124,27 @@ def _worker(rank, world, port, K, n, S, h, d, inject, mode, ret, use_comm=False)
         ok = ok and torch.equal(first, full_prop[f0])
         if Kl > 1:
             ok = ok and torch.equal(rest, want.view(3, Kl, n, S, D)[:, 1:].reshape(3 * (Kl - 1) * n, S, D))
+        # ---- the in-place form of the two-pass order: producers write into the halo-extended buffers, ONE grouped
+        #      neighbour exchange per block, the propagation waits for it
+        ext = sh.ext_alloc(S, D, q.dtype, q.device)
+        o = 1 if world > 1 else 0
+        ext[0][o:].copy_(piv[f0:f0 + Kl])
+        fake.pivot_inv_norm(ext[0][o:], out=ext[1][o:])
+        fake.calls.clear()
+        pe, ie, ke, reqs = sh.pivotal_block(loc(q), loc(k), loc(v), h_, d ** -0.5, inject, ext, mode=mode)
+        parts = [c[3] if len(c) > 3 else "all" for c in fake.calls if c[0] == "ext_attn"]
+        ok = ok and parts == (["source", "bank"] if (mode or sh.auto_mode(h_, S)) == "heads" else ["all"])
+        ok = ok and torch.equal(ke.view(3, Kl + o, S, D)[:, o:].reshape(3 * Kl, S, D), loc(full_attn))
+        ke.view(3, Kl + o, S, D)[:, o:].copy_(loc(kf_out).view(3, Kl, S, D))   # the propagation data of this test
+        reqs2 = sh._p2p([ke.view(3, Kl + o, S, D)[b, -1] for b in range(3)],
+                        [ke.view(3, Kl + o, S, D)[b, 0] for b in range(3)]) if world > 1 else []
+        sh.halo_wait(reqs2)
+        first, rest = sh.propagate_all(tgt_all, res_all, pe, ie, ke, w, n, halo_reqs=reqs)
+        ok = ok and torch.equal(first, full_prop[f0])
+        if Kl > 1:
+            ok = ok and torch.equal(rest, want.view(3, Kl, n, S, D)[:, 1:].reshape(3 * (Kl - 1) * n, S, D))
+        if rank > 0:          # the halo slot holds the left neighbour's last keyframe: pivots, inverse norms, output
+            ok = ok and torch.equal(pe[0], piv[f0 - 1]) and torch.equal(ie[0], inv[f0 - 1])
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()

@@ -36,7 +36,12 @@ __device__ __forceinline__ float ln_store8(T* p, const float (&f)[8]) {
         v8 v;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            v[i] = (T)f[i];
+            // the fp32 value exists as such before it is rounded (torch: fp32 layer_norm, then the cast).  Without the
+            // barrier hipcc fuses `(f16)fmaf(..)` into v_fma_mixlo_f16 in one translation unit and emits v_pk_fma_f32 +
+            // v_cvt_pk_f16_f32 in the other, and the two differ in rare elements (seen on MI355X, f16 only)
+            float t = f[i];
+            asm("" : "+v"(t));
+            v[i] = (T)t;
             ss = fmaf((float)v[i], (float)v[i], ss);
         }
         st16(p, __builtin_bit_cast(u32x4, v));

@@ -230,14 +230,18 @@ def head_unpack(recv: torch.Tensor, dsts: Sequence[torch.Tensor]) -> None:
             ctypes.cast(fs, ctypes.c_void_p), nb, W, Kl, S, hd, ld, recv.element_size())
 
 
-def pivot_inv_norm(piv: torch.Tensor) -> torch.Tensor:
-    """1/||row|| for pivots [..., D] (bf16/f16, contiguous) -> fp32 [...]."""
-    dev = _need_gpu(piv)
+def pivot_inv_norm(piv: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """1/||row|| for pivots [..., D] (bf16/f16, contiguous) -> fp32 [...] (written into `out` when given: a
+    contiguous fp32 tensor of that shape, e.g. slots of a halo-extended buffer)."""
+    dev = _need_gpu(piv, out)
     lib = _lib.load()
     piv = piv.contiguous()
     D = piv.shape[-1]
     rows = piv.numel() // D
-    out = torch.empty(piv.shape[:-1], dtype=torch.float32, device=piv.device)
+    if out is None:
+        out = torch.empty(piv.shape[:-1], dtype=torch.float32, device=piv.device)
+    elif out.dtype != torch.float32 or out.shape != piv.shape[:-1] or not out.is_contiguous():
+        raise ValueError("pivot_inv_norm: `out` must be a contiguous fp32 tensor of shape piv.shape[:-1]")
     _launch(dev, "tf_pivot_inv_norm", lib.tf_pivot_inv_norm, piv.data_ptr(), out.data_ptr(), rows, D, _DT[piv.dtype])
     return out
 

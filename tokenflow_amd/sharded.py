@@ -57,17 +57,37 @@ class _Done:
         return True
 
 
+class _EventRing:
+    """A few reusable events for ordering the exchange stream against the compute stream.  Creating a
+    `torch.cuda.Event` costs tens of microseconds on this stack (`Stream.wait_stream` creates one per call: it was
+    half of a rank's host time per block, profiles/r03_rank_step_v1.txt); recording an existing one costs ~1 us.  A
+    wait captures the record that is current when it is issued, so an event may be re-recorded while earlier waits on
+    it are still queued; a handle that is waited on only after its event has been re-recorded (the ring wrapped)
+    waits for that LATER point of the same in-order stream -- still correct, never early.  256 events cover more than
+    two passes over the 16 blocks (<= 6 per block), longer than any handle lives (a halo is waited for in the
+    propagation pass that follows its pivotal pass)."""
+
+    def __init__(self, n: int = 256):
+        self._ev = [torch.cuda.Event() for _ in range(n)]
+        self._i = 0
+
+    def next(self):
+        e = self._ev[self._i]
+        self._i = (self._i + 1) % len(self._ev)
+        return e
+
+
 class _StreamWork:
     """Completion handle of exchanges issued on the side stream: wait() orders the CURRENT stream behind them
     (no host blocking -- the semantics of a c10d work object on the NCCL backend)."""
 
-    def __init__(self, stream, device):
-        self.stream, self.device = stream, device
+    def __init__(self, event, device):
+        self.event, self.device = event, device
 
     def wait(self):
         # current_stream(device): the device-less form resolves the device through torch.cuda.is_available(),
         # ~30 us per call on this stack -- it was two thirds of a rank's host time per block
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        torch.cuda.current_stream(self.device).wait_event(self.event)
         return True
 
 
@@ -139,11 +159,16 @@ class FrameShard:
         cur = torch.cuda.current_stream(dev)
         if getattr(self, "_cs", None) is None:
             self._cs = torch.cuda.Stream(device=dev)
-        self._cs.wait_stream(cur)
+            self._ring = _EventRing()
+        e = self._ring.next()
+        e.record(cur)
+        self._cs.wait_event(e)
         fn(self._cs.cuda_stream)
         for t in tensors:
             t.record_stream(self._cs)          # allocator: not reusable before the exchange stream is done with it
-        return _StreamWork(self._cs, dev)
+        done = self._ring.next()
+        done.record(self._cs)
+        return _StreamWork(done, dev)
 
     def _a2a(self, recv: torch.Tensor, send: torch.Tensor, out_rows=None, in_rows=None, async_op: bool = False):
         """Row all-to-all over dim 0: out_rows[p] rows arrive from peer p, in_rows[p] rows go to peer p (None = equal)."""
@@ -225,18 +250,22 @@ class FrameShard:
         return "bank" if S <= 64 else "heads"
 
     def pivotal_attention(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool,
-                          mode: Optional[str] = None):
+                          mode: Optional[str] = None, out4: Optional[torch.Tensor] = None):
         """Extended attention for the local keyframes against all K keyframes -> [3*Kl,S,D].
-        mode: "heads" | "bank" | None (= `auto_mode`, chosen per block)."""
+        mode: "heads" | "bank" | None (= `auto_mode`, chosen per block).
+        out4: a [3,Kl,S,D] view (dense frames, free branch stride) the result is written into in place -- the
+        keyframe slots 1.. of a halo-extended buffer (`ext_alloc`); returned as is."""
         if self.world == 1:
-            return ops.ext_attn(q_local, k_local, v_local, heads, scale, inject)
+            if out4 is None:
+                return ops.ext_attn(q_local, k_local, v_local, heads, scale, inject)
+            return ops.ext_attn(q_local, k_local, v_local, heads, scale, inject, out=out4.view(q_local.shape))
         if mode is None:
             mode = self.auto_mode(heads, q_local.shape[1])
         if mode == "heads":
-            return self._pivotal_heads(q_local, k_local, v_local, heads, scale, inject)
-        return self._pivotal_bank(q_local, k_local, v_local, heads, scale, inject)
+            return self._pivotal_heads(q_local, k_local, v_local, heads, scale, inject, out4)
+        return self._pivotal_bank(q_local, k_local, v_local, heads, scale, inject, out4)
 
-    def _pivotal_bank(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool):
+    def _pivotal_bank(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool, out4=None):
         """One gather (`_bank_gather`), one attention call on the gathered buffer in place; q keeps its own layout
         (its token stride is independent of the bank's)."""
         B, S, D = q_local.shape
@@ -246,12 +275,12 @@ class FrameShard:
         if q.stride(2) != 1 or q.stride(0) != S * q.stride(1):
             q = q.contiguous()
         q4 = q.view(3, Kl, S, D) if q.is_contiguous() else q.unflatten(0, (3, Kl))
-        out = torch.empty(3, Kl, S, D, dtype=q.dtype, device=q.device)
+        out = torch.empty(3, Kl, S, D, dtype=q.dtype, device=q.device) if out4 is None else out4
         ops.ext_attn_views(q4, kv, vv, out, heads, scale, inject, "all", q_frame0=self.kf0,
                            no_split=not self.attn_split)
-        return out.view(3 * Kl, S, D)
+        return out.view(3 * Kl, S, D) if out4 is None else out4
 
-    def _pivotal_heads(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool):
+    def _pivotal_heads(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool, out4=None):
         """Frames <-> heads re-sharding.  Launches per block on this rank: ONE pack kernel, the source-branch
         attention (overlaps the first all-to-all), the bank attention reading the received buffer IN PLACE and
         writing the second all-to-all's send buffer IN PLACE (strided views, no re-layout copies), ONE unpack
@@ -283,9 +312,13 @@ class FrameShard:
         work = self._a2a(recv.view(K, -1), send.view(W * Kl, -1),
                          None if even else self.counts, None if even else [Kl] * W, async_op=True)
         # ---- source branch: own-frame keys, all heads, stays local (overlaps the exchange)
-        out = torch.empty(3, Kl, S, D, dtype=dt, device=dev)
-        ops.ext_attn(q_local, k_local, v_local, heads, scale, inject, out=out.view(3 * Kl, S, D), part="source",
-                     no_split=not self.attn_split)
+        if out4 is None:
+            out = torch.empty(3, Kl, S, D, dtype=dt, device=dev)
+            ops.ext_attn(q_local, k_local, v_local, heads, scale, inject, out=out.view(3 * Kl, S, D), part="source",
+                         no_split=not self.attn_split)
+        else:            # straight into the caller's (strided) slots: the strided entry point
+            out = out4
+            ops.ext_attn_views(q3, k3, v3, out, heads, scale, inject, "source", no_split=not self.attn_split)
         work.wait()
         # ---- bank branches on this rank's head group, all K frames: read `recv`, write `send2`, both in place
         rp = recv.permute(1, 0, 2, 3)                                   # [ns, K, S, hd] view
@@ -302,7 +335,39 @@ class FrameShard:
         self._a2a(recv2.view(W * Kl, -1), send2.view(K, -1),
                   None if even else [Kl] * W, None if even else self.counts)
         ops.head_unpack(recv2, [out[1], out[2]])
-        return out.view(3 * Kl, S, D)
+        return out.view(3 * Kl, S, D) if out4 is None else out4
+
+    # ------------------------------------------------------------------ pivotal pass of one block, in place
+    def ext_alloc(self, S: int, D: int, dtype: torch.dtype, device):
+        """Per-block state of the propagation, halo slot included: (pivots [Kl+o,S,D], inverse norms [Kl+o,S] fp32,
+        cached attention output [3,Kl+o,S,D]) with o = 1 when there is a left neighbour to hear from (world > 1), else
+        0.  The producers write the local keyframes straight into slots o.. (norm1 -> pivots and inverse norms, the
+        attention -> its output): no staging copy on either side of the halo exchange."""
+        o = 1 if self.world > 1 else 0
+        Kl = self.Kl
+        return (torch.empty(Kl + o, S, D, dtype=dtype, device=device),
+                torch.empty(Kl + o, S, dtype=torch.float32, device=device),
+                torch.empty(3, Kl + o, S, D, dtype=dtype, device=device))
+
+    def pivotal_block(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool, ext,
+                      mode: Optional[str] = None):
+        """The pivotal pass of one block on this rank, for the reference's call order (one pivotal pass over all
+        blocks, then the chunk passes): `ext` = `ext_alloc(...)` whose pivot / inverse-norm slots o.. the caller has
+        filled.  The attention writes its output into ext's slots o.. in place, then ONE grouped neighbour exchange
+        carries the last local keyframe's pivots, inverse norms and attention output to slot 0 of rank r+1 (it has the
+        rest of the pivotal pass to arrive; nothing waits for it before the propagation).
+        Returns (pivots ext, inverse norms ext, attention output ext [3(Kl+o),S,D], pending requests) -- the
+        arguments of `propagate_all(..., halo_reqs=)`."""
+        piv, inv, kfo = ext
+        o = 1 if self.world > 1 else 0
+        Kl = self.Kl
+        S, D = piv.shape[1:]
+        self.pivotal_attention(q_local, k_local, v_local, heads, scale, inject, mode=mode, out4=kfo[:, o:])
+        reqs = []
+        if self.world > 1:
+            reqs = self._p2p([piv[-1], inv[-1], kfo[0, -1], kfo[1, -1], kfo[2, -1]],
+                             [piv[0], inv[0], kfo[0, 0], kfo[1, 0], kfo[2, 0]])
+        return piv, inv, kfo.view(3 * (Kl + o), S, D), reqs
 
     # ------------------------------------------------------------------ halo for propagation
     def exchange_halo(self, pivots_local: torch.Tensor, inv_local: torch.Tensor, kf_out_local: torch.Tensor):
