@@ -65,10 +65,12 @@ def parse():
     ap.add_argument("--config", default="cfg2", choices=list(workload.CONFIGS))
     ap.add_argument("--pivotal-exchange", default="auto", choices=["auto", "heads", "bank"],
                     help="N > 1: how the pivotal pass is exchanged (sharded.py); auto = heads when they divide")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo", "hip"],
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo", "hip", "native"],
                     help="N > 1: nccl (= RCCL through torch.distributed, the default); hip = the exchange steps through "
                          "the library's C ABI (tf_comm_*: RCCL without torch.distributed on the data path; gloo carries "
-                         "only the barrier and the unique id); gloo lets several ranks share one GPU on a development "
+                         "only the barrier and the unique id); native = hip plus the pivotal pass of a block as ONE library "
+                         "call (tf_rank_pivotal: pack, exchanges, attention, unpack, halo issued by native code; a second "
+                         "communicator carries the halo); gloo lets several ranks share one GPU on a development "
                          "box (functional check of the N > 1 path, its timing means nothing)")
     ap.add_argument("--no-attn-split", action="store_true",
                     help="N > 1: keep the rank's attention in its one-pass form (FrameShard's default: bit-identical to "
@@ -436,7 +438,7 @@ def parity_check(cfg, blocks, w):
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: become `torch.distributed.run` with N ranks on this node."""
     n_dev = torch.cuda.device_count()
-    if args.backend in ("nccl", "hip") and n_dev < args.gpus:
+    if args.backend in ("nccl", "hip", "native") and n_dev < args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible "
                  f"(use --backend gloo to let ranks share a GPU for a functional check)")
     with socket.socket() as s:
@@ -468,13 +470,21 @@ def main():
         else:
             dist.init_process_group("gloo")
     cfg = workload.CONFIGS[args.config]
-    hip_comm = None
-    if world > 1 and args.backend == "hip":
+    hip_comm = halo_comm = None
+    if world > 1 and args.backend in ("hip", "native"):
         from tokenflow_amd.comm import HipComm
         uid = [HipComm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)          # control plane only: the tensors never touch gloo
         hip_comm = HipComm(uid[0], rank, world)
-    shard = sharded.FrameShard(cfg.K, comm=hip_comm, attn_split=world > 1 and not args.no_attn_split)
+        if args.backend == "native":                    # the halo on a communicator of its own (see rank_exec.hip)
+            uid = [HipComm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            halo_comm = HipComm(uid[0], rank, world)
+    split = world > 1 and not args.no_attn_split
+    if world > 1 and args.backend == "native":
+        shard = sharded.NativeShard(cfg.K, hip_comm, halo_comm, attn_split=split)
+    else:
+        shard = sharded.FrameShard(cfg.K, comm=hip_comm, attn_split=split)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     blocks = [Block(cfg, lvl, inj, shard, gen, dev) for lvl, inj in workload.BLOCKS]
     w = blend_w(cfg.chunk, dev)
@@ -586,7 +596,8 @@ def main():
                    "launch": "HIP-graph replay" if use_graph else "eager",
                    "parallelism": "1 GPU" if world == 1 else
                    "frames sharded over %d GPUs; pivotal pass: %s%s; rank attention %s" % (
-                       world, exch_name, "; exchanges through the C ABI (tf_comm_*)" if hip_comm is not None else "",
+                       world, exch_name, ("; one library call per block (tf_rank_pivotal)" if args.backend == "native" else
+                                         "; exchanges through the C ABI (tf_comm_*)") if hip_comm is not None else "",
                        "split over extra workgroups + merge (equal to 1 GPU within the output rounding)"
                        if shard.attn_split else "one-pass (bit-identical to 1 GPU)"),
                    "step_algorithmic_tflop": round((fa + fn) / 1e12, 2),
@@ -607,8 +618,11 @@ def main():
             lv = [int(x) for x in args.cpu_sample_levels.split(",") if x != ""]
             out["cpu_baseline"] = cpu_baseline(cfg, lv)
         print(json.dumps(out), flush=True)
-    if hip_comm is not None:
-        hip_comm.close()
+    if isinstance(shard, sharded.NativeShard):
+        shard.close()
+    for c in (halo_comm, hip_comm):
+        if c is not None:
+            c.close()
     if world > 1:
         dist.destroy_process_group()
 

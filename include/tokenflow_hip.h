@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TF_ABI_VERSION 3
+#define TF_ABI_VERSION 4
 
 /* element types */
 #define TF_BF16 0
@@ -315,6 +315,30 @@ int tf_inject_copy(void* x, int64_t elems_per_branch, int elem_bytes, void* stre
 typedef struct tf_comm tf_comm;
 int tf_comm_unique_id(void* id_out_128_bytes);
 int tf_comm_init(const void* unique_id_128_bytes, int rank, int world, tf_comm** comm_out);
+
+/* Two more transports behind the same exchange entry points (no RCCL needed for either):
+ *   tf_comm_init_hooks     a host-provided transport -- the exchanges are handed to the function table (sizes in
+ *                          BYTES, device pointers, the stream the caller's work is ordered on; a function returns 0 or
+ *                          an error code that surfaces as TF_ERR_COMM).  For hosts with their own fabric (MPI ...);
+ *                          the multi-process tests of this repository carry it over gloo to run W ranks on one GPU.
+ *   tf_comm_init_loopback  the wire-less stand-in: every exchange becomes device-to-device copies, on the stream, of
+ *                          the sizes a real rank of a `world`-GPU run would receive, out of this rank's own buffers.
+ *                          A rank's complete launch / stream / buffer sequence on ONE GPU: for timing the host and GPU
+ *                          side of a rank (tools/rank_step_microbench.py); the received DATA is meaningless for
+ *                          world > 1.
+ * The peer arithmetic (rank, world, row counts) is the callers' in all three. */
+#define TF_MAX_WORLD 64
+typedef struct tf_comm_hooks {
+    int (*all_to_all_rows)(void* user, const void* send, void* recv, const int64_t* send_rows, const int64_t* recv_rows,
+                           int64_t row_bytes, void* stream);
+    int (*allgather_rows)(void* user, const void* local, void* bank, const int64_t* rows, int64_t row_bytes,
+                          void* stream);
+    int (*sendrecv)(void* user, const void* const* send, const int64_t* send_bytes, int n_send, int send_peer,
+                    void* const* recv, const int64_t* recv_bytes, int n_recv, int recv_peer, void* stream);
+    void* user;
+} tf_comm_hooks;
+int tf_comm_init_hooks(const tf_comm_hooks* hooks, int rank, int world, tf_comm** comm_out);
+int tf_comm_init_loopback(int rank, int world, tf_comm** comm_out);
 int tf_comm_destroy(tf_comm* comm);
 int tf_comm_rank(const tf_comm* comm);
 int tf_comm_world(const tf_comm* comm);
@@ -325,6 +349,50 @@ int tf_all_to_all_rows(tf_comm* comm, const void* send, void* recv, const int64_
                        int64_t row_elems, int dtype, void* stream);
 int tf_sendrecv_pivot(tf_comm* comm, const void* const* send, const int64_t* send_elems, int n_send, int send_peer,
                       void* const* recv, const int64_t* recv_elems, int n_recv, int recv_peer, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * One rank's pivotal pass of a block, issued by ONE host call  --  the native form of tokenflow_amd/sharded.py's
+ * `pivotal_block` (no counterpart in the single-process reference; what is computed is tokenflow_utils.py:124-197
+ * for the rank's keyframes against the bank of all K).  Rank r of W owns a contiguous run of the K keyframes (the
+ * first K % W ranks one more); per block it
+ *   TF_RANK_HEADS  packs head group w of its keyframes' q / k / v for every rank w (tf_head_pack), exchanges them
+ *                  (tf_all_to_all_rows), computes the source branch of its own frames meanwhile,
+ *                  the uncond / cond branches of ITS head group over all K frames in place on the received buffer
+ *                  (tf_ext_attn_fwd_strided, TF_ATTN_BANK_ONLY), sends the outputs back and unpacks them
+ *                  (tf_head_unpack); needs H % W == 0 and one token stride for q, k, v;
+ *   TF_RANK_BANK   gathers the K/V slabs of all ranks (tf_allgather_rows) and computes its own keyframes' queries
+ *                  against the gathered bank: one collective, 4x the bytes; any head count;
+ * then sends its last keyframe's pivot features, inverse norms and attention output to rank r+1 (tf_sendrecv_pivot on
+ * the halo communicator and a stream of its own: chunk c of the propagation reads keyframes c and c-1, 331-333).
+ *
+ *   q, k, v   : the rank's local [3, Kl, S, H*Dh] projections; strides (elements) =
+ *               { q_branch, q_frame, k_branch, k_frame, v_branch, v_frame, q_token, kv_token }
+ *   piv_ext   : [Kl+o, S, H*Dh] 16-bit, inv_ext : float [Kl+o, S], kfo_ext : [3, Kl+o, S, H*Dh] 16-bit, o = 1 for
+ *               W > 1 else 0: the per-block state of the propagation with the halo slot in front.  The caller has
+ *               written the local keyframes' pivots / inverse norms into slots o..; the call writes the attention
+ *               output into slots o.. of kfo_ext and the neighbour's last keyframe arrives in slot 0 of all three.
+ *   flags     : TF_ATTN_INJECT / TF_ATTN_NO_SPLIT / TF_ATTN_FOLD_SCALE as for tf_ext_attn_fwd
+ *   slot      : names this block's halo exchange, 0 <= slot < TF_RANK_SLOTS: tf_rank_halo_wait(rk, slot, stream) orders
+ *               `stream` behind it (call it before the propagation reads slot 0; no host blocking)
+ *   ws        : tf_rank_pivotal_workspace_bytes; holds the exchange buffers, so ONE workspace serves consecutive
+ *               blocks of one stream (each use is complete before the next block touches it), not concurrent ones.
+ * tf_rank_create makes two streams (exchange, halo) and the events on the CURRENT device; `comm` may be NULL (one rank: plain
+ * tf_ext_attn_fwd into kfo_ext), `halo_comm` NULL = comm (a second communicator lets the halo of block b travel
+ * beside the exchanges of block b+1: collectives of one RCCL communicator execute in issue order).
+ * ------------------------------------------------------------------------ */
+#define TF_RANK_HEADS 0
+#define TF_RANK_BANK 1
+#define TF_RANK_SLOTS 64
+typedef struct tf_rank tf_rank;
+int tf_rank_create(tf_comm* comm, tf_comm* halo_comm, int K, tf_rank** rank_out);
+int tf_rank_destroy(tf_rank* rk);
+int tf_rank_local_keyframes(const tf_rank* rk);
+int tf_rank_first_keyframe(const tf_rank* rk);
+size_t tf_rank_pivotal_workspace_bytes(const tf_rank* rk, int S, int H, int Dh, int dtype);
+int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const void* v, const int64_t* strides, void* piv_ext,
+                    float* inv_ext, void* kfo_ext, int S, int H, int Dh, float scale, int flags, int dtype, int mode,
+                    int slot, void* ws, size_t ws_bytes, void* stream);
+int tf_rank_halo_wait(tf_rank* rk, int slot, void* stream);
 
 #ifdef __cplusplus
 }

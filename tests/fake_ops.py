@@ -56,7 +56,7 @@ class FakeOps:
         return out
 
     def ext_attn_views(self, q, k, v, out, heads, scale, inject, part="all", branch0=(0, 0, 0, 0), q_frame0=0,
-                       fold_scale=None, no_split=None):
+                       fold_scale=None, no_split=None, stream=None):
         """Strided 4-D views [branches b0.., frames, S, D]: materialise dense [3F,S,D] tensors (branches a call
         may not read stay NaN), run `ext_attn`, scatter the computed branches into the `out` view."""
         K, Kq, S, D = k.shape[1], q.shape[1], k.shape[2], k.shape[3]

@@ -276,3 +276,127 @@ def test_frame_shard_over_c_abi_comm_single_rank():
     finally:
         ops.NO_SPLIT = old
         c.close()
+
+
+def _native_worker(rank, world, port, K, h, inject, mode, split, ret):
+    """`NativeShard` (one tf_rank_pivotal call per block) on `world` processes sharing cuda:0, exchanges through the
+    library's host-transport entry points carried by gloo (tests/gloo_transport.py)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.gloo_transport import gloo_comm
+        from tokenflow_amd import ops, sharded
+        ops.NO_SPLIT = True
+        n, S, d = 2, 192, 40
+        D = h * d
+        g = torch.Generator().manual_seed(0)
+        q, k, v = (torch.randn(3 * K, S, D, generator=g).bfloat16().cuda() for _ in range(3))
+        piv = torch.nn.functional.layer_norm(torch.randn(K, S, D, generator=g), (D,)).bfloat16().cuda()
+        tgt = [(piv[c].float()[torch.randperm(S, generator=g).cuda()].repeat(n, 1)
+                + 0.1 * torch.randn(n * S, D, generator=g).cuda()).bfloat16() for c in range(K)]
+        res = [torch.randn(3 * n, S, D, generator=g).bfloat16().cuda() for _ in range(K)]
+        s = torch.arange(0, n)
+        w = torch.sigmoid(torch.abs(s + n - n // 2) / (torch.abs(s - n // 2) + torch.abs(s + n - n // 2))).cuda()
+        full = ops.ext_attn(q, k, v, h, d ** -0.5, inject)
+        inv = ops.pivot_inv_norm(piv)
+        one = sharded.FrameShard.__new__(sharded.FrameShard)
+        one.group, one.world, one.rank, one.K, one.Kl, one.kf0 = None, 1, 0, K, K, 0
+        ref = [one.propagate(c, tgt[c], res[c], piv, inv, full, w, n) for c in range(K)]
+
+        comm, halo_comm = gloo_comm(rank, world), gloo_comm(rank, world)
+        sh = sharded.NativeShard(K, comm, halo_comm, attn_split=split)
+        py = sharded.FrameShard(K, comm=comm, attn_split=split)          # the Python form on the same transport
+        Kl, f0 = sh.Kl, sh.kf0
+        o = 1 if world > 1 else 0
+        loc = lambda t: t.view(3, K, S, D)[:, f0:f0 + Kl].reshape(3 * Kl, S, D)
+        tgt_all = torch.cat([tgt[f0 + j] for j in range(Kl)])
+        res_all = torch.stack([res[f0 + j].view(3, n, S, D) for j in range(Kl)], dim=1).reshape(3 * Kl * n, S, D)
+        want = torch.stack([ref[f0 + j].float().view(3, n, S, D) for j in range(Kl)], dim=1).reshape(3 * Kl * n, S, D)
+        ok = True
+        outs = []
+        for shard in (sh, py):
+            ext = shard.ext_alloc(S, D, torch.bfloat16, piv.device)
+            for t in ext:
+                t.view(torch.int16 if t.dtype == torch.bfloat16 else torch.int32).fill_(0x7fc0 if t.dtype == torch.bfloat16 else 0x7fc00000)  # NaN
+            ext[0][o:].copy_(piv[f0:f0 + Kl])
+            ops.pivot_inv_norm(ext[0][o:], out=ext[1][o:])
+            pe, ie, ke, reqs = shard.pivotal_block(loc(q), loc(k), loc(v), h, d ** -0.5, inject, ext, mode=mode)
+            first, rest = shard.propagate_all(tgt_all, res_all, pe, ie, ke, w, n, halo_reqs=reqs)
+            torch.cuda.synchronize()
+            got = ke.view(3, Kl + o, S, D)[:, o:].reshape(3 * Kl, S, D)
+            outs.append((got.clone(), pe.clone(), ie.clone(), ke.clone(), first.clone()))
+            if not split:          # one-pass attention: the single-GPU result bit for bit
+                ok = ok and torch.equal(got, loc(full)) and torch.equal(first, ref[f0])
+                if Kl > 1:
+                    ok = ok and torch.equal(rest, want.view(3, Kl, n, S, D)[:, 1:].reshape(3 * (Kl - 1) * n, S, D))
+            else:
+                a, r = got.float(), loc(full).float()
+                ok = ok and bool(((a - r).abs() <= 2.0 ** -7 * r.abs() + 1e-3).all())
+            if rank > 0:           # the halo slot holds the left neighbour's last keyframe
+                ok = ok and torch.equal(pe[0], piv[f0 - 1]) and torch.equal(ie[0], inv[f0 - 1])
+                if not split:
+                    ok = ok and torch.equal(ke.view(3, Kl + o, S, D)[:, 0], full.view(3, K, S, D)[:, f0 - 1])
+        # native and Python forms: the same bits in every buffer they fill (the unset halo slot of rank 0 excluded)
+        lo = 0 if rank > 0 else o
+        (got_n, pe_n, ie_n, ke_n, first_n), (got_p, pe_p, ie_p, ke_p, first_p) = outs
+        ok = ok and torch.equal(got_n, got_p) and torch.equal(first_n, first_p)
+        ok = ok and torch.equal(pe_n[lo:], pe_p[lo:]) and torch.equal(ie_n[lo:], ie_p[lo:])
+        ok = ok and torch.equal(ke_n.view(3, Kl + o, S, D)[:, lo:], ke_p.view(3, Kl + o, S, D)[:, lo:])
+        sh.close()
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,K,h,mode,inject,split", [
+    (2, 4, 2, "heads", False, False), (2, 4, 2, "heads", True, False), (2, 5, 2, "heads", True, False),
+    (2, 5, 2, "bank", False, False), (2, 4, 2, "bank", True, False), (2, 4, 2, "heads", False, True),
+    (8, 8, 8, "heads", False, False), (8, 8, 8, "heads", True, False), (8, 8, 8, "bank", True, False),
+    (8, 25, 5, "bank", False, False), (8, 8, 8, None, False, True)])
+def test_native_rank_executor(world, K, h, mode, inject, split):
+    """tf_rank_pivotal (csrc/rank_exec.hip) through `NativeShard`: the whole pivotal pass of a block -- pack, both
+    exchanges, source and bank attention, unpack, neighbour halo -- issued by one library call, on 2 and on 8
+    processes sharing one GPU (BASELINE configs 3 and 5 at their own rank geometry: one keyframe per rank; runs of
+    4,3,3,3,3,3,3,3 with 5 heads -> bank form).  Equal to the single-GPU result bit for bit in the one-pass form, and to
+    the Python `FrameShard` on the same transport bit for bit in every form."""
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_native_worker, args=(world, port, K, h, inject, mode, split, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_native_rank_executor_single_rank_and_loopback():
+    """World of one (no communicator: plain attention into the extended buffer) and the wire-less loopback transport
+    at 'rank 3 of 8' (results meaningless by construction; every launch, size check and stream hand-over runs)."""
+    from tokenflow_amd import ops, sharded
+    from tokenflow_amd.comm import HipComm
+    K, S, h, d = 8, 256, 8, 40
+    D = h * d
+    g = torch.Generator().manual_seed(5)
+    q, k, v = (torch.randn(3 * K, S, D, generator=g).bfloat16().cuda() for _ in range(3))
+    sh = sharded.NativeShard(K, None)
+    ext = sh.ext_alloc(S, D, torch.bfloat16, q.device)
+    for inject in (False, True):
+        pe, ie, ke, reqs = sh.pivotal_block(q, k, v, h, d ** -0.5, inject, ext)
+        assert reqs == [] and torch.equal(ke, ops.ext_attn(q, k, v, h, d ** -0.5, inject, no_split=True))
+    sh.close()
+    for mode in ("heads", "bank"):
+        comm = HipComm.loopback(3, 8)
+        sh = sharded.NativeShard(K, comm, attn_split=True)
+        assert (sh.Kl, sh.kf0) == (1, 3)
+        ext = sh.ext_alloc(S, D, torch.bfloat16, q.device)
+        ext[0][1:].normal_()
+        ops.pivot_inv_norm(ext[0][1:], out=ext[1][1:])
+        ql, kl, vl = (t.view(3, K, S, D)[:, 3:4].reshape(3, S, D) for t in (q, k, v))
+        for inject in (False, True):
+            pe, ie, ke, reqs = sh.pivotal_block(ql, kl, vl, h, d ** -0.5, inject, ext, mode=mode)
+            for r in reqs:
+                r.wait()
+        torch.cuda.synchronize()
+        # the source branch never leaves the rank: exact whatever the transport
+        want = ops.ext_attn(ql, kl, vl, h, d ** -0.5, False, part="source", no_split=True)
+        assert torch.equal(ke.view(3, 2, S, D)[0, 1], want[0])
+        sh.close()
+        comm.close()

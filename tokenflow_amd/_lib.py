@@ -10,7 +10,8 @@ TF_BF16, TF_F16, TF_F32 = 0, 1, 2
 TF_ATTN_INJECT, TF_ATTN_EXACT_SCALE, TF_ATTN_BANK_ONLY, TF_ATTN_SOURCE_ONLY, TF_ATTN_NO_SPLIT = 1, 2, 4, 8, 16
 TF_ATTN_OUT_F32 = 32
 TF_ATTN_FOLD_SCALE = 64
-ABI_VERSION = 3
+ABI_VERSION = 4
+TF_RANK_HEADS, TF_RANK_BANK, TF_RANK_SLOTS = 0, 1, 64
 TF_ERR_COMM = -6
 
 _c = ctypes
@@ -56,6 +57,17 @@ _SIGNATURES = {
     "tf_all_to_all_rows": (_c.c_int, [_c.c_void_p] * 5 + [_c.c_int64, _c.c_int, _c.c_void_p]),
     "tf_sendrecv_pivot": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p,
                                      _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+    "tf_comm_init_hooks": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p]),
+    "tf_comm_init_loopback": (_c.c_int, [_c.c_int, _c.c_int, _c.c_void_p]),
+    # one rank's pivotal pass of a block in one call (csrc/rank_exec.hip; tokenflow_amd/sharded.py NativeShard)
+    "tf_rank_create": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p]),
+    "tf_rank_destroy": (_c.c_int, [_c.c_void_p]),
+    "tf_rank_local_keyframes": (_c.c_int, [_c.c_void_p]),
+    "tf_rank_first_keyframe": (_c.c_int, [_c.c_void_p]),
+    "tf_rank_pivotal_workspace_bytes": (_c.c_size_t, [_c.c_void_p] + [_c.c_int] * 4),
+    "tf_rank_pivotal": (_c.c_int, [_c.c_void_p] * 8 + [_c.c_int] * 3 + [_c.c_float] + [_c.c_int] * 4 +
+                        [_c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "tf_rank_halo_wait": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

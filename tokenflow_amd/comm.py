@@ -39,6 +39,22 @@ def _dev(*ts: torch.Tensor) -> int:
     return _DT[ts[0].dtype]
 
 
+_I64P = ctypes.POINTER(ctypes.c_int64)
+_VPP = ctypes.POINTER(ctypes.c_void_p)
+# the function table of a host-provided transport (tf_comm_hooks, include/tokenflow_hip.h): sizes in BYTES
+A2A_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _I64P, _I64P, ctypes.c_int64,
+                          ctypes.c_void_p)
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _I64P, ctypes.c_int64,
+                                ctypes.c_void_p)
+SENDRECV_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, _VPP, _I64P, ctypes.c_int, ctypes.c_int, _VPP, _I64P,
+                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p)
+
+
+class _Hooks(ctypes.Structure):
+    _fields_ = [("all_to_all_rows", A2A_FN), ("allgather_rows", ALLGATHER_FN), ("sendrecv", SENDRECV_FN),
+                ("user", ctypes.c_void_p)]
+
+
 class HipComm:
     def __init__(self, unique_id: bytes, rank: int, world: int):
         if len(unique_id) != 128:
@@ -48,6 +64,31 @@ class HipComm:
         buf = ctypes.create_string_buffer(unique_id, 128)
         _lib.check(lib.tf_comm_init(buf, rank, world, ctypes.byref(h)), "tf_comm_init")
         self._h, self.rank, self.world = h, rank, world
+
+    @classmethod
+    def loopback(cls, rank: int, world: int) -> "HipComm":
+        """The wire-less stand-in (tf_comm_init_loopback): every exchange becomes device-to-device copies of the sizes a
+        rank of a `world`-GPU run receives, out of this rank's own buffers.  For timing one rank's launch sequence on
+        one GPU (tools/rank_step_microbench.py); the received data is meaningless for world > 1."""
+        self = cls.__new__(cls)
+        h = ctypes.c_void_p()
+        _lib.check(_lib.load().tf_comm_init_loopback(rank, world, ctypes.byref(h)), "tf_comm_init_loopback")
+        self._h, self.rank, self.world = h, rank, world
+        return self
+
+    @classmethod
+    def from_hooks(cls, rank: int, world: int, all_to_all_rows, allgather_rows, sendrecv) -> "HipComm":
+        """A host-provided transport (tf_comm_init_hooks): three Python callables with the signatures of A2A_FN /
+        ALLGATHER_FN / SENDRECV_FN (device pointers, sizes in bytes, the stream; return 0).  The multi-process tests
+        carry it over gloo so that W ranks can share one GPU."""
+        self = cls.__new__(cls)
+        self._fns = (A2A_FN(all_to_all_rows), ALLGATHER_FN(allgather_rows), SENDRECV_FN(sendrecv))   # kept alive
+        self._hooks = _Hooks(self._fns[0], self._fns[1], self._fns[2], None)
+        h = ctypes.c_void_p()
+        _lib.check(_lib.load().tf_comm_init_hooks(ctypes.byref(self._hooks), rank, world, ctypes.byref(h)),
+                   "tf_comm_init_hooks")
+        self._h, self.rank, self.world = h, rank, world
+        return self
 
     @staticmethod
     def unique_id() -> bytes:

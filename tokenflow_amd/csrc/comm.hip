@@ -59,10 +59,51 @@ int elem_bytes(int dtype) { return dtype == TF_F32 ? 4 : 2; }
 
 }  // namespace
 
+// Transport behind a communicator: RCCL (the product), a host-provided function table (tf_comm_init_hooks: an MPI
+// host, the gloo-carried transport of the multi-process tests), or the wire-less stand-in (tf_comm_init_loopback:
+// every exchange becomes same-size device-to-device copies on the stream -- the launch sequence, buffers and stream
+// hand-overs of a rank of a W-GPU run on ONE GPU, for timing only: the data a world > 1 loopback "receives" is its own).
+enum { COMM_RCCL = 0, COMM_HOOKS = 1, COMM_LOOPBACK = 2 };
+
 struct tf_comm {
     ncclComm_t comm;
     int rank, world;
+    int kind = COMM_RCCL;
+    tf_comm_hooks hooks = {};
 };
+
+namespace {
+
+int copy_async(void* dst, const void* src, size_t bytes, hipStream_t st, const char* what) {
+    if (bytes == 0 || dst == src) return 0;
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) {
+        tf_set_error("%s: hipMemcpyAsync: %s", what, hipGetErrorString(e));
+        return (int)e;   // > 0: a HIP error code, as for launch failures
+    }
+    return 0;
+}
+
+// loopback forms: one copy per message a real rank would receive, of that message's size, from this rank's own data
+int loop_allgather_rows(const tf_comm* c, const void* local, void* bank, const int64_t* rows, size_t rb, hipStream_t st) {
+    char* r = static_cast<char*>(bank);
+    const size_t mine = (size_t)rows[c->rank] * rb;
+    for (int p = 0; p < c->world; ++p) {
+        const size_t n = (size_t)rows[p] * rb;
+        if (const int rc = copy_async(r, local, n < mine ? n : mine, st, "tf_allgather_rows(loopback)")) return rc;
+        r += n;
+    }
+    return 0;
+}
+
+int loop_all_to_all(const tf_comm* c, const void* send, void* recv, const int64_t* send_rows, const int64_t* recv_rows,
+                    size_t rb, hipStream_t st) {
+    size_t ns = 0, nr = 0;
+    for (int p = 0; p < c->world; ++p) ns += (size_t)send_rows[p] * rb, nr += (size_t)recv_rows[p] * rb;
+    return copy_async(recv, send, ns < nr ? ns : nr, st, "tf_all_to_all_rows(loopback)");
+}
+
+}  // namespace
 
 #define TF_NEED_RCCL(what)                                                                          \
     const Rccl& R = rccl();                                                                         \
@@ -118,8 +159,33 @@ extern "C" int tf_comm_init(const void* unique_id, int rank, int world, tf_comm*
     return 0;
 }
 
+extern "C" int tf_comm_init_hooks(const tf_comm_hooks* hooks, int rank, int world, tf_comm** comm_out) {
+    TF_ARG(hooks && comm_out, TF_ERR_NULL, "tf_comm_init_hooks: null pointer");
+    TF_ARG(hooks->all_to_all_rows && hooks->allgather_rows && hooks->sendrecv, TF_ERR_NULL,
+           "tf_comm_init_hooks: a transport needs all three entry points");
+    TF_ARG(world > 0 && rank >= 0 && rank < world, TF_ERR_SHAPE, "tf_comm_init_hooks: rank %d of %d", rank, world);
+    tf_comm* c = new tf_comm{nullptr, rank, world};
+    c->kind = COMM_HOOKS;
+    c->hooks = *hooks;
+    *comm_out = c;
+    return 0;
+}
+
+extern "C" int tf_comm_init_loopback(int rank, int world, tf_comm** comm_out) {
+    TF_ARG(comm_out, TF_ERR_NULL, "tf_comm_init_loopback: null pointer");
+    TF_ARG(world > 0 && rank >= 0 && rank < world, TF_ERR_SHAPE, "tf_comm_init_loopback: rank %d of %d", rank, world);
+    tf_comm* c = new tf_comm{nullptr, rank, world};
+    c->kind = COMM_LOOPBACK;
+    *comm_out = c;
+    return 0;
+}
+
 extern "C" int tf_comm_destroy(tf_comm* comm) {
     if (!comm) return 0;
+    if (comm->kind != COMM_RCCL) {
+        delete comm;
+        return 0;
+    }
     TF_NEED_RCCL("tf_comm_destroy");
     const ncclResult_t r = R.CommDestroy(comm->comm);
     delete comm;
@@ -138,6 +204,12 @@ extern "C" int tf_allgather_kv(tf_comm* comm, const void* local, void* bank, int
     TF_ARG(comm && local && bank, TF_ERR_NULL, "tf_allgather_kv: null pointer");
     TF_ARG(dtype == TF_BF16 || dtype == TF_F16 || dtype == TF_F32, TF_ERR_DTYPE, "tf_allgather_kv: dtype %d", dtype);
     TF_ARG(elems_per_rank > 0, TF_ERR_SHAPE, "tf_allgather_kv: elems_per_rank=%lld", (long long)elems_per_rank);
+    if (comm->kind != COMM_RCCL) {   // the other transports know the row form only: one row of equal size per rank
+        int64_t rows[TF_MAX_WORLD];
+        TF_ARG(comm->world <= TF_MAX_WORLD, TF_ERR_SHAPE, "tf_allgather_kv: world %d > %d", comm->world, TF_MAX_WORLD);
+        for (int p = 0; p < comm->world; ++p) rows[p] = 1;
+        return tf_allgather_rows(comm, local, bank, rows, elems_per_rank, dtype, stream);
+    }
     TF_NEED_RCCL("tf_allgather_kv");
     // bytes, not typed elements: a gather moves data, and ncclBfloat16 needs no special casing this way
     TF_NCCL(R.AllGather(local, bank, (size_t)elems_per_rank * elem_bytes(dtype), ncclUint8, comm->comm,
@@ -153,9 +225,15 @@ extern "C" int tf_allgather_rows(tf_comm* comm, const void* local, void* bank, c
     TF_ARG(row_elems > 0, TF_ERR_SHAPE, "tf_allgather_rows: row_elems=%lld", (long long)row_elems);
     for (int p = 0; p < comm->world; ++p)
         TF_ARG(rows[p] >= 0, TF_ERR_SHAPE, "tf_allgather_rows: negative row count, peer %d", p);
-    TF_NEED_RCCL("tf_allgather_rows");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t rb = (size_t)row_elems * elem_bytes(dtype);
+    if (comm->kind == COMM_HOOKS) {
+        const int rc = comm->hooks.allgather_rows(comm->hooks.user, local, bank, rows, (int64_t)rb, stream);
+        if (rc) tf_set_error("tf_allgather_rows: the host transport returned %d", rc);
+        return rc ? TF_ERR_COMM : 0;
+    }
+    if (comm->kind == COMM_LOOPBACK) return loop_allgather_rows(comm, local, bank, rows, rb, st);
+    TF_NEED_RCCL("tf_allgather_rows");
     const size_t mine = (size_t)rows[comm->rank] * rb;
     char* r = static_cast<char*>(bank);
     TF_NCCL(R.GroupStart(), "tf_allgather_rows");
@@ -174,13 +252,19 @@ extern "C" int tf_all_to_all_rows(tf_comm* comm, const void* send, void* recv, c
     TF_ARG(comm && send && recv && send_rows && recv_rows, TF_ERR_NULL, "tf_all_to_all_rows: null pointer");
     TF_ARG(dtype == TF_BF16 || dtype == TF_F16 || dtype == TF_F32, TF_ERR_DTYPE, "tf_all_to_all_rows: dtype %d", dtype);
     TF_ARG(row_elems > 0, TF_ERR_SHAPE, "tf_all_to_all_rows: row_elems=%lld", (long long)row_elems);
-    TF_NEED_RCCL("tf_all_to_all_rows");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t rb = (size_t)row_elems * elem_bytes(dtype);
     const char* s = static_cast<const char*>(send);
     char* r = static_cast<char*>(recv);
     for (int p = 0; p < comm->world; ++p)
         TF_ARG(send_rows[p] >= 0 && recv_rows[p] >= 0, TF_ERR_SHAPE, "tf_all_to_all_rows: negative row count, peer %d", p);
+    if (comm->kind == COMM_HOOKS) {
+        const int rc = comm->hooks.all_to_all_rows(comm->hooks.user, send, recv, send_rows, recv_rows, (int64_t)rb, stream);
+        if (rc) tf_set_error("tf_all_to_all_rows: the host transport returned %d", rc);
+        return rc ? TF_ERR_COMM : 0;
+    }
+    if (comm->kind == COMM_LOOPBACK) return loop_all_to_all(comm, send, recv, send_rows, recv_rows, rb, st);
+    TF_NEED_RCCL("tf_all_to_all_rows");
     TF_NCCL(R.GroupStart(), "tf_all_to_all_rows");
     ncclResult_t first = ncclSuccess;
     for (int p = 0; p < comm->world; ++p) {
@@ -202,9 +286,27 @@ extern "C" int tf_sendrecv_pivot(tf_comm* comm, const void* const* send, const i
     TF_ARG(n_send >= 0 && n_recv >= 0 && send_peer < comm->world && recv_peer < comm->world, TF_ERR_SHAPE,
            "tf_sendrecv_pivot: n_send=%d n_recv=%d peers=(%d,%d) world=%d", n_send, n_recv, send_peer, recv_peer,
            comm->world);
-    TF_NEED_RCCL("tf_sendrecv_pivot");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t eb = elem_bytes(dtype);
+    if (comm->kind == COMM_HOOKS) {
+        int64_t sb[16], rbs[16];
+        TF_ARG(n_send <= 16 && n_recv <= 16, TF_ERR_SHAPE, "tf_sendrecv_pivot: more than 16 messages");
+        for (int i = 0; i < n_send; ++i) sb[i] = send_elems[i] * (int64_t)eb;
+        for (int i = 0; i < n_recv; ++i) rbs[i] = recv_elems[i] * (int64_t)eb;
+        const int rc = comm->hooks.sendrecv(comm->hooks.user, send, sb, n_send, send_peer, recv, rbs, n_recv, recv_peer,
+                                            stream);
+        if (rc) tf_set_error("tf_sendrecv_pivot: the host transport returned %d", rc);
+        return rc ? TF_ERR_COMM : 0;
+    }
+    if (comm->kind == COMM_LOOPBACK) {   // what arrives has the size of what the left neighbour sends: this rank's own
+        if (recv_peer >= 0 && send_peer >= 0)
+            for (int i = 0; i < n_recv && i < n_send; ++i) {
+                const size_t n = (size_t)(recv_elems[i] < send_elems[i] ? recv_elems[i] : send_elems[i]) * eb;
+                if (const int rc = copy_async(recv[i], send[i], n, st, "tf_sendrecv_pivot(loopback)")) return rc;
+            }
+        return 0;
+    }
+    TF_NEED_RCCL("tf_sendrecv_pivot");
     TF_NCCL(R.GroupStart(), "tf_sendrecv_pivot");
     ncclResult_t first = ncclSuccess;
     if (send_peer >= 0)

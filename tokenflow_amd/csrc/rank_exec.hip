@@ -1,0 +1,323 @@
+// One rank's pivotal pass of a transformer block in a frame-sharded multi-GPU run, issued by ONE host call.
+//
+// The reference is single-process; tokenflow_amd/sharded.py describes the partitioning
+// (tokenflow_utils.py:133-138: every keyframe's queries read the keys / values of ALL K keyframes; 331-333: chunk c
+// reads keyframes c and c-1) and is the Python form of the same sequence.  This file is that sequence as native
+// code: the per-block work of a rank at 8 GPUs is a dozen launches of 5..500 us with three exchanges between them,
+// and a Python host spends 200-300 us per block issuing them (profiles/r03_rank_step_v2.txt) -- more than the GPU
+// needs for the block at three of the four UNet levels.  Here the host cost is one foreign call.
+//
+// Streams: the caller's stream carries the compute; the frames<->heads / bank exchanges run on an exchange stream,
+// the neighbour halo on a halo stream (with its own communicator when the host gives one: collectives of ONE RCCL
+// communicator execute in issue order, and a 10 MB halo message in front of the next block's all-to-all would sit on
+// the critical path).  The source-branch attention stays on the caller's stream, between the issue of the first
+// exchange and the wait for it (an auxiliary compute stream for it was measured on the Python path: no gain at the
+// coarse levels, -4 % at level 0 where its workgroups take slots from the chip-filling bank grid).  All ordering is by
+// events; no host synchronisation anywhere.
+#include <new>
+
+#include "tf_common.h"
+
+struct tf_comm;   // csrc/comm.hip
+
+namespace {
+
+constexpr int RING = 64;
+
+int hip_fail(const char* what, hipError_t e) {
+    tf_set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+#define TF_HIP(call, what)                                   \
+    do {                                                     \
+        const hipError_t e_ = (call);                        \
+        if (e_ != hipSuccess) return hip_fail(what, e_);     \
+    } while (0)
+
+inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+struct tf_rank {
+    tf_comm* comm;
+    tf_comm* halo_comm;
+    int K, world, rank, Kl, kf0;
+    int counts[TF_MAX_WORLD];
+    hipStream_t xs = nullptr, hs = nullptr;   // exchange, halo
+    hipEvent_t ring[RING];
+    int ring_i = 0;
+    hipEvent_t halo_done[TF_RANK_SLOTS];
+    bool halo_set[TF_RANK_SLOTS];
+
+    hipEvent_t next() {
+        hipEvent_t e = ring[ring_i];
+        ring_i = (ring_i + 1) % RING;
+        return e;
+    }
+};
+
+namespace {
+
+// `to` continues after everything enqueued on `from` so far.  Events are reused: a wait captures the record that is
+// current when it is issued (HIP semantics), and 64 events outlast any hand-over of a block.
+int order(tf_rank* rk, hipStream_t from, hipStream_t to, const char* what) {
+    hipEvent_t e = rk->next();
+    TF_HIP(hipEventRecord(e, from), what);
+    TF_HIP(hipStreamWaitEvent(to, e, 0), what);
+    return 0;
+}
+
+struct Layout {   // exchange buffers of one call inside the caller's workspace
+    size_t send, recv, send2, recv2, ws_bank, ws_src, total;
+    size_t ws_bank_bytes, ws_src_bytes;
+};
+
+Layout layout(const tf_rank* rk, int S, int H, int Dh, int dtype, int mode) {
+    const size_t eb = 2;
+    const int W = rk->world, Kl = rk->Kl, K = rk->K;
+    const size_t D = (size_t)H * Dh;
+    Layout L{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += up256(bytes);
+        return at;
+    };
+    if (mode == TF_RANK_HEADS) {
+        const size_t hd = D / W;
+        L.send = take((size_t)W * Kl * 6 * S * hd * eb);
+        L.recv = take((size_t)K * 6 * S * hd * eb);
+        L.send2 = take((size_t)K * 2 * S * hd * eb);
+        L.recv2 = take((size_t)W * Kl * 2 * S * hd * eb);
+        L.ws_bank_bytes = tf_ext_attn_workspace_bytes(K, S, H / W, Dh, dtype);
+        L.ws_src_bytes = tf_ext_attn_workspace_bytes(Kl, S, H, Dh, dtype);
+        L.ws_bank = take(L.ws_bank_bytes);
+        L.ws_src = take(L.ws_src_bytes);
+    } else {
+        L.send = take((size_t)Kl * 6 * S * D * eb);
+        L.recv = take((size_t)K * 6 * S * D * eb);
+        L.ws_bank_bytes = tf_ext_attn_workspace_bytes(K, S, H, Dh, dtype);
+        L.ws_bank = take(L.ws_bank_bytes);
+    }
+    L.total = off;
+    return L;
+}
+
+}  // namespace
+
+extern "C" int tf_rank_create(tf_comm* comm, tf_comm* halo_comm, int K, tf_rank** out) {
+    TF_ARG(out, TF_ERR_NULL, "tf_rank_create: null pointer");
+    const int world = comm ? tf_comm_world(comm) : 1, rank = comm ? tf_comm_rank(comm) : 0;
+    TF_ARG(world >= 1 && world <= TF_MAX_WORLD && K >= world, TF_ERR_SHAPE,
+           "tf_rank_create: %d keyframes over %d ranks (every rank owns at least one; at most %d ranks)", K, world,
+           TF_MAX_WORLD);
+    TF_ARG(!halo_comm || (tf_comm_world(halo_comm) == world && tf_comm_rank(halo_comm) == rank), TF_ERR_SHAPE,
+           "tf_rank_create: the halo communicator must have the same rank and world");
+    tf_rank* rk = new (std::nothrow) tf_rank();
+    TF_ARG(rk, TF_ERR_NULL, "tf_rank_create: out of memory");
+    rk->comm = comm;
+    rk->halo_comm = halo_comm ? halo_comm : comm;
+    rk->K = K, rk->world = world, rk->rank = rank;
+    int off = 0;
+    for (int r = 0; r < world; ++r) {   // contiguous runs, the first K % W ranks hold one more (sharded.py)
+        rk->counts[r] = K / world + (r < K % world ? 1 : 0);
+        if (r == rank) rk->kf0 = off;
+        off += rk->counts[r];
+    }
+    rk->Kl = rk->counts[rank];
+    for (int i = 0; i < TF_RANK_SLOTS; ++i) rk->halo_set[i] = false, rk->halo_done[i] = nullptr;
+    for (int i = 0; i < RING; ++i) rk->ring[i] = nullptr;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < RING && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&rk->ring[i], hipEventDisableTiming);
+    for (int i = 0; i < TF_RANK_SLOTS && e == hipSuccess; ++i)
+        e = hipEventCreateWithFlags(&rk->halo_done[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&rk->xs, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&rk->hs, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        tf_rank_destroy(rk);
+        return hip_fail("tf_rank_create", e);
+    }
+    *out = rk;
+    return 0;
+}
+
+extern "C" int tf_rank_destroy(tf_rank* rk) {
+    if (!rk) return 0;
+    for (hipStream_t s : {rk->xs, rk->hs})
+        if (s) {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamDestroy(s);
+        }
+    for (int i = 0; i < RING; ++i)
+        if (rk->ring[i]) (void)hipEventDestroy(rk->ring[i]);
+    for (int i = 0; i < TF_RANK_SLOTS; ++i)
+        if (rk->halo_done[i]) (void)hipEventDestroy(rk->halo_done[i]);
+    delete rk;
+    return 0;
+}
+
+extern "C" int tf_rank_local_keyframes(const tf_rank* rk) { return rk ? rk->Kl : 0; }
+extern "C" int tf_rank_first_keyframe(const tf_rank* rk) { return rk ? rk->kf0 : 0; }
+
+extern "C" size_t tf_rank_pivotal_workspace_bytes(const tf_rank* rk, int S, int H, int Dh, int dtype) {
+    if (!rk || S <= 0 || H <= 0 || Dh <= 0 || dtype == TF_F32) return 0;
+    if (rk->world == 1) return up256(tf_ext_attn_workspace_bytes(rk->K, S, H, Dh, dtype));
+    const size_t bank = layout(rk, S, H, Dh, dtype, TF_RANK_BANK).total;
+    const size_t heads = H % rk->world == 0 ? layout(rk, S, H, Dh, dtype, TF_RANK_HEADS).total : 0;
+    return bank > heads ? bank : heads;
+}
+
+extern "C" int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const void* v, const int64_t* st_in,
+                               void* piv_ext, float* inv_ext, void* kfo_ext, int S, int H, int Dh, float scale,
+                               int flags, int dtype, int mode, int slot, void* ws, size_t ws_bytes, void* stream) {
+    TF_ARG(rk && q && k && v && st_in && piv_ext && inv_ext && kfo_ext && ws, TF_ERR_NULL, "tf_rank_pivotal: null pointer");
+    TF_ARG(dtype == TF_BF16 || dtype == TF_F16, TF_ERR_DTYPE, "tf_rank_pivotal: dtype %d (bf16/f16 only)", dtype);
+    TF_ARG(mode == TF_RANK_HEADS || mode == TF_RANK_BANK, TF_ERR_SHAPE, "tf_rank_pivotal: mode %d", mode);
+    TF_ARG(slot >= 0 && slot < TF_RANK_SLOTS, TF_ERR_SHAPE, "tf_rank_pivotal: slot %d outside [0, %d)", slot, TF_RANK_SLOTS);
+    TF_ARG(!(flags & (TF_ATTN_BANK_ONLY | TF_ATTN_SOURCE_ONLY)), TF_ERR_SHAPE,
+           "tf_rank_pivotal: the part flags are the executor's own");
+    TF_ARG(ws_bytes >= tf_rank_pivotal_workspace_bytes(rk, S, H, Dh, dtype), TF_ERR_WORKSPACE,
+           "tf_rank_pivotal: workspace %zu < %zu bytes", ws_bytes, tf_rank_pivotal_workspace_bytes(rk, S, H, Dh, dtype));
+    const int W = rk->world, Kl = rk->Kl, K = rk->K, o = W > 1 ? 1 : 0;
+    const int64_t D = (int64_t)H * Dh, SD = (int64_t)S * D;
+    const int64_t q_bs = st_in[0], q_fs = st_in[1], k_bs = st_in[2], k_fs = st_in[3], v_bs = st_in[4], v_fs = st_in[5],
+                  ld_q = st_in[6], ld = st_in[7];
+    typedef unsigned short E;   // any 16-bit element: only pointer arithmetic happens here
+    const E* qe = static_cast<const E*>(q);
+    const E* ke = static_cast<const E*>(k);
+    const E* ve = static_cast<const E*>(v);
+    E* kfo = static_cast<E*>(kfo_ext);
+    E* piv = static_cast<E*>(piv_ext);
+    unsigned char* wsb = static_cast<unsigned char*>(ws);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t o_bs = (int64_t)(Kl + o) * SD;   // branch stride of the halo-extended attention output
+    E* out_loc = kfo + (int64_t)o * SD;            // its local slots
+    const int inject = flags & TF_ATTN_INJECT;
+    rk->halo_set[slot] = false;
+
+    if (W == 1) {
+        const int64_t strides[9] = {q_bs, q_fs, k_bs, k_fs, v_bs, v_fs, o_bs, SD, ld_q};
+        return tf_ext_attn_fwd_strided(q, k, v, out_loc, K, K, 0, S, H, Dh, ld, strides, scale, flags, dtype, ws, ws_bytes,
+                                       stream);
+    }
+    int64_t cnt[TF_MAX_WORLD], own[TF_MAX_WORLD];
+    for (int p = 0; p < W; ++p) cnt[p] = rk->counts[p], own[p] = Kl;
+
+    if (mode == TF_RANK_HEADS) {
+        TF_ARG(H % W == 0, TF_ERR_SHAPE, "tf_rank_pivotal: %d heads do not divide over %d ranks (use TF_RANK_BANK)", H, W);
+        TF_ARG(ld_q == ld, TF_ERR_SHAPE, "tf_rank_pivotal: the head re-sharding packs q, k, v with one token stride");
+        const Layout L = layout(rk, S, H, Dh, dtype, TF_RANK_HEADS);
+        const int Hl = H / W;
+        const int64_t hd = D / W, Shd = (int64_t)S * hd;
+        E* send = reinterpret_cast<E*>(wsb + L.send);
+        E* recv = reinterpret_cast<E*>(wsb + L.recv);
+        E* send2 = reinterpret_cast<E*>(wsb + L.send2);
+        E* recv2 = reinterpret_cast<E*>(wsb + L.recv2);
+        // ---- pack: head group w of every slab the bank branches read, frame-major (slab order [q.., k.., v..])
+        const void* slabs[6];
+        int64_t fss[6];
+        int ns;
+        if (inject) {   // source q, k (what uncond and cond use, tokenflow_utils.py:124-130) and the two value banks
+            ns = 4;
+            slabs[0] = qe, slabs[1] = ke, slabs[2] = ve + v_bs, slabs[3] = ve + 2 * v_bs;
+            fss[0] = q_fs, fss[1] = k_fs, fss[2] = v_fs, fss[3] = v_fs;
+        } else {
+            ns = 6;
+            slabs[0] = qe + q_bs, slabs[1] = qe + 2 * q_bs, slabs[2] = ke + k_bs, slabs[3] = ke + 2 * k_bs;
+            slabs[4] = ve + v_bs, slabs[5] = ve + 2 * v_bs;
+            fss[0] = fss[1] = q_fs, fss[2] = fss[3] = k_fs, fss[4] = fss[5] = v_fs;
+        }
+        if (const int rc = tf_head_pack(slabs, fss, ns, send, W, Kl, S, (int)hd, ld, 2, stream)) return rc;
+        // ---- first all-to-all (exchange stream) and, under it, the source branch of the local frames
+        if (const int rc = order(rk, st, rk->xs, "tf_rank_pivotal")) return rc;
+        if (const int rc = tf_all_to_all_rows(rk->comm, send, recv, own, cnt, ns * Shd, dtype, rk->xs)) return rc;
+        hipEvent_t arrived = rk->next();
+        TF_HIP(hipEventRecord(arrived, rk->xs), "tf_rank_pivotal");
+        {
+            const int64_t strides[9] = {q_bs, q_fs, k_bs, k_fs, v_bs, v_fs, o_bs, SD, ld_q};
+            if (const int rc = tf_ext_attn_fwd_strided(q, k, v, out_loc, Kl, Kl, 0, S, H, Dh, ld, strides, scale,
+                                                       flags | TF_ATTN_SOURCE_ONLY, dtype, wsb + L.ws_src, L.ws_src_bytes,
+                                                       stream))
+                return rc;
+        }
+        // ---- bank branches on this rank's head group, all K frames: read `recv`, write `send2`, both in place
+        TF_HIP(hipStreamWaitEvent(st, arrived, 0), "tf_rank_pivotal");
+        {
+            const int64_t fs_r = ns * Shd;          // frame stride of recv [K][ns][S][hd]
+            const E *qb, *kb, *vb;
+            if (inject)
+                qb = recv, kb = recv + Shd, vb = recv + 2 * Shd - Shd;          // v slabs 2, 3 are branches 1, 2
+            else
+                qb = recv - Shd, kb = recv + 2 * Shd - Shd, vb = recv + 4 * Shd - Shd;   // slabs (0,1), (2,3), (4,5)
+            E* ob = send2 - Shd;                                                 // send2 [K][uncond|cond][S][hd]
+            const int64_t strides[9] = {Shd, fs_r, Shd, fs_r, Shd, fs_r, Shd, 2 * Shd, hd};
+            if (const int rc = tf_ext_attn_fwd_strided(qb, kb, vb, ob, K, K, 0, S, Hl, Dh, hd, strides, scale,
+                                                       flags | TF_ATTN_BANK_ONLY, dtype, wsb + L.ws_bank, L.ws_bank_bytes,
+                                                       stream))
+                return rc;
+        }
+        // ---- outputs back to the frame owners
+        if (const int rc = order(rk, st, rk->xs, "tf_rank_pivotal")) return rc;
+        if (const int rc = tf_all_to_all_rows(rk->comm, send2, recv2, cnt, own, 2 * Shd, dtype, rk->xs)) return rc;
+        if (const int rc = order(rk, rk->xs, st, "tf_rank_pivotal")) return rc;
+        void* dsts[2] = {out_loc + o_bs, out_loc + 2 * o_bs};
+        const int64_t dfs[2] = {SD, SD};
+        if (const int rc = tf_head_unpack(recv2, dsts, dfs, 2, W, Kl, S, (int)hd, D, 2, stream)) return rc;
+    } else {
+        // ---- ONE collective: the slabs the attention reads across frames, gathered into [K][slabs][S][D]
+        const Layout L = layout(rk, S, H, Dh, dtype, TF_RANK_BANK);
+        E* send = reinterpret_cast<E*>(wsb + L.send);
+        E* recv = reinterpret_cast<E*>(wsb + L.recv);
+        const void* slabs[6];
+        int64_t fss[6];
+        int ns;
+        if (inject) {
+            ns = 4;
+            slabs[0] = ke, slabs[1] = ve, slabs[2] = ve + v_bs, slabs[3] = ve + 2 * v_bs;
+            fss[0] = k_fs, fss[1] = fss[2] = fss[3] = v_fs;
+        } else {
+            ns = 6;
+            slabs[0] = ke, slabs[1] = ke + k_bs, slabs[2] = ke + 2 * k_bs;
+            slabs[3] = ve, slabs[4] = ve + v_bs, slabs[5] = ve + 2 * v_bs;
+            fss[0] = fss[1] = fss[2] = k_fs, fss[3] = fss[4] = fss[5] = v_fs;
+        }
+        if (const int rc = tf_head_pack(slabs, fss, ns, send, 1, Kl, S, (int)D, ld, 2, stream)) return rc;
+        if (const int rc = order(rk, st, rk->xs, "tf_rank_pivotal")) return rc;
+        if (const int rc = tf_allgather_rows(rk->comm, send, recv, cnt, ns * SD, dtype, rk->xs)) return rc;
+        if (const int rc = order(rk, rk->xs, st, "tf_rank_pivotal")) return rc;
+        const int64_t fs_r = ns * SD;
+        const E* kb = recv;
+        const E* vb = recv + (inject ? 1 : 3) * SD;
+        const int64_t strides[9] = {q_bs, q_fs, SD, fs_r, SD, fs_r, o_bs, SD, ld_q};
+        if (const int rc = tf_ext_attn_fwd_strided(q, kb, vb, out_loc, K, Kl, rk->kf0, S, H, Dh, D, strides, scale, flags,
+                                                   dtype, wsb + L.ws_bank, L.ws_bank_bytes, stream))
+            return rc;
+    }
+
+    // ---- neighbour halo: the last local keyframe's pivots, inverse norms and attention output -> slot 0 of rank r+1
+    const int to = rk->rank + 1 < W ? rk->rank + 1 : -1, from = rk->rank > 0 ? rk->rank - 1 : -1;
+    if (to >= 0 || from >= 0) {
+        if (const int rc = order(rk, st, rk->hs, "tf_rank_pivotal")) return rc;
+        const void* s16[4] = {piv + (int64_t)Kl * SD, kfo + (int64_t)Kl * SD, kfo + o_bs + (int64_t)Kl * SD,
+                              kfo + 2 * o_bs + (int64_t)Kl * SD};
+        void* r16[4] = {piv, kfo, kfo + o_bs, kfo + 2 * o_bs};
+        const int64_t n16[4] = {SD, SD, SD, SD};
+        if (const int rc = tf_sendrecv_pivot(rk->halo_comm, s16, n16, 4, to, r16, n16, 4, from, dtype, rk->hs)) return rc;
+        const void* s32[1] = {inv_ext + (int64_t)Kl * S};
+        void* r32[1] = {inv_ext};
+        const int64_t n32[1] = {S};
+        if (const int rc = tf_sendrecv_pivot(rk->halo_comm, s32, n32, 1, to, r32, n32, 1, from, TF_F32, rk->hs)) return rc;
+        TF_HIP(hipEventRecord(rk->halo_done[slot], rk->hs), "tf_rank_pivotal");
+        rk->halo_set[slot] = true;
+    }
+    return 0;
+}
+
+extern "C" int tf_rank_halo_wait(tf_rank* rk, int slot, void* stream) {
+    TF_ARG(rk, TF_ERR_NULL, "tf_rank_halo_wait: null pointer");
+    TF_ARG(slot >= 0 && slot < TF_RANK_SLOTS, TF_ERR_SHAPE, "tf_rank_halo_wait: slot %d outside [0, %d)", slot,
+           TF_RANK_SLOTS);
+    if (rk->halo_set[slot])
+        TF_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), rk->halo_done[slot], 0), "tf_rank_halo_wait");
+    return 0;
+}

@@ -27,15 +27,16 @@ def _need_gpu(*ts):
     return dev
 
 
-def _launch(dev, what: str, fn, *args):
+def _launch(dev, what: str, fn, *args, stream: Optional[int] = None):
     """Call a C-ABI entry point whose last argument is the stream: the launch goes to the CURRENT stream OF THE
-    TENSORS' DEVICE, with that device made current for the duration of the call when it is not already (a kernel
-    enqueued on another device's stream with foreign pointers faults or corrupts memory)."""
+    TENSORS' DEVICE (or to `stream`, a raw HIP stream of that device, when the caller orders its own streams), with
+    that device made current for the duration of the call when it is not already (a kernel enqueued on another
+    device's stream with foreign pointers faults or corrupts memory)."""
     if dev.index != torch.cuda.current_device():
         with torch.cuda.device(dev):
-            rc = fn(*args, torch.cuda.current_stream(dev).cuda_stream)
+            rc = fn(*args, torch.cuda.current_stream(dev).cuda_stream if stream is None else stream)
     else:
-        rc = fn(*args, torch.cuda.current_stream(dev).cuda_stream)
+        rc = fn(*args, torch.cuda.current_stream(dev).cuda_stream if stream is None else stream)
     if rc != 0:
         _lib.check(rc, what)
 
@@ -49,17 +50,19 @@ _ws_cache = {}
 _attn_ws_bytes = {}   # (K, S, H, Dh, dtype) -> scratch bytes of tf_ext_attn_fwd (a pure function of the shape)
 
 
-def _workspace(nbytes: int, device, tag: str = "attn") -> torch.Tensor:
+def _workspace(nbytes: int, device, tag: str = "attn", stream: Optional[int] = None) -> torch.Tensor:
     """Scratch for one launch, cached per (purpose, device, stream).  While a HIP graph is being captured the
     buffer comes from the graph's private pool and must live and die with that graph: never cached."""
-    if device.index != torch.cuda.current_device():      # capture state is a property of the TENSORS' device's stream
-        with torch.cuda.device(device):
+    if stream is None:
+        if device.index != torch.cuda.current_device():      # capture state is a property of the TENSORS' device's stream
+            with torch.cuda.device(device):
+                capturing = torch.cuda.is_current_stream_capturing()
+        else:
             capturing = torch.cuda.is_current_stream_capturing()
-    else:
-        capturing = torch.cuda.is_current_stream_capturing()
-    if capturing:
-        return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
-    key = (tag, device.index, torch.cuda.current_stream(device).cuda_stream)
+        if capturing:
+            return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+    key = (tag, device.index, stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -154,12 +157,15 @@ def _view_base(t: torch.Tensor, b0: int, S: int, what: str):
 
 def ext_attn_views(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, heads: int, scale: float,
                    inject: bool, part: str = "all", branch0=(0, 0, 0, 0), q_frame0: int = 0,
-                   fold_scale: Optional[bool] = None, no_split: Optional[bool] = None) -> torch.Tensor:
+                   fold_scale: Optional[bool] = None, no_split: Optional[bool] = None,
+                   stream: Optional[int] = None) -> torch.Tensor:
     """`ext_attn` on strided 4-D views [branches, frames, S, D] (tf_ext_attn_fwd_strided): q, k, v are read where
     a collective left them and `out` is written where the next one sends from -- no re-layout copies.  Each view
     holds the branches `branch0[i] ..` of its tensor (q, k, v, out in that order; e.g. a bank-only call passes the
     uncond/cond slabs with branch0 = 1, and under injection the single source slab of q and k with branch0 = 0).
-    Branch and frame strides are free; k and v share one token stride, q has its own, out is dense (= D)."""
+    Branch and frame strides are free; k and v share one token stride, q has its own, out is dense (= D).
+    stream: a raw HIP stream of the tensors' device to launch on instead of torch's current one (the caller orders it
+    against the others itself: sharded.py runs the source branch beside the bank exchange)."""
     dev = _need_gpu(q, k, v, out)
     lib = _lib.load()
     S, D = k.shape[2], k.shape[3]
@@ -185,10 +191,11 @@ def ext_attn_views(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch
     nbytes = _attn_ws_bytes.get(key)
     if nbytes is None:
         nbytes = _attn_ws_bytes[key] = lib.tf_ext_attn_workspace_bytes(K, S, heads, dh, dt)
-    ws = _workspace(nbytes, q.device)
+    ws = _workspace(nbytes, q.device, stream=stream)
     strides = (ctypes.c_int64 * 9)(q_bs, q_fs, k_bs, k_fs, v_bs, v_fs, o_bs, o_fs, ld_q)
     _launch(dev, "tf_ext_attn_fwd_strided", lib.tf_ext_attn_fwd_strided, qp, kp, vp, op, K, Kq, int(q_frame0), S, heads,
-            dh, ld, ctypes.cast(strides, ctypes.c_void_p), float(scale), flags, dt, ws.data_ptr(), ws.numel())
+            dh, ld, ctypes.cast(strides, ctypes.c_void_p), float(scale), flags, dt, ws.data_ptr(), ws.numel(),
+            stream=stream)
     return out
 
 

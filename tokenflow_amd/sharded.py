@@ -43,6 +43,7 @@ TOKENFLOW_SHARD_ATTN_SPLIT=1) lets the small grid of a rank split the bank over 
 and merge: faster, and equal to the single-GPU result only within the output
 rounding, because the merge re-associates fp32 sums.
 """
+import ctypes
 import os
 from typing import Optional, Tuple
 
@@ -116,6 +117,10 @@ class FrameShard:
         if attn_split is None:
             attn_split = os.environ.get("TOKENFLOW_SHARD_ATTN_SPLIT", "0") not in ("", "0")
         self.attn_split = bool(attn_split)
+        # TOKENFLOW_SHARD_SRC_AUX=1: the source-branch attention of the head re-sharding on an auxiliary stream, beside
+        # the bank attention (in-place form only).  Measured on a rank of 8 (profiles/r03_rank_step_v3.txt): no gain at
+        # the coarse levels and -4 % at level 0 (its workgroups take slots from the chip-filling bank grid) -> off.
+        self.src_aux = os.environ.get("TOKENFLOW_SHARD_SRC_AUX", "0") not in ("", "0")
         self.group = group
         self.comm = comm                       # tokenflow_amd.comm.HipComm: exchanges through the C ABI instead
         self._cs = None                        # its side stream
@@ -168,6 +173,23 @@ class FrameShard:
             t.record_stream(self._cs)          # allocator: not reusable before the exchange stream is done with it
         done = self._ring.next()
         done.record(self._cs)
+        return _StreamWork(done, dev)
+
+    def _on_aux(self, dev, tensors, fn):
+        """Run `fn(raw stream)` on this rank's auxiliary compute stream, ordered after everything already enqueued on
+        the current stream; returns the handle whose wait() orders the current stream behind it."""
+        cur = torch.cuda.current_stream(dev)
+        if getattr(self, "_aux", None) is None:
+            self._aux = torch.cuda.Stream(device=dev)
+            self._aux_ring = _EventRing(64)
+        e = self._aux_ring.next()
+        e.record(cur)
+        self._aux.wait_event(e)
+        fn(self._aux.cuda_stream)
+        for t in tensors:
+            t.record_stream(self._aux)
+        done = self._aux_ring.next()
+        done.record(self._aux)
         return _StreamWork(done, dev)
 
     def _a2a(self, recv: torch.Tensor, send: torch.Tensor, out_rows=None, in_rows=None, async_op: bool = False):
@@ -292,6 +314,7 @@ class FrameShard:
         if heads % W:
             raise ValueError(f"{heads} heads do not divide over {W} ranks")
         hd, dev, dt = D // W, q_local.device, q_local.dtype
+        src_done = None
 
         def frames(t):     # [3*Kl, S, D] (token stride free) -> [3, Kl, S, D] view
             if t.stride(2) != 1 or t.stride(0) != S * t.stride(1):
@@ -318,7 +341,14 @@ class FrameShard:
                          no_split=not self.attn_split)
         else:            # straight into the caller's (strided) slots: the strided entry point
             out = out4
-            ops.ext_attn_views(q3, k3, v3, out, heads, scale, inject, "source", no_split=not self.attn_split)
+            if q3.is_cuda and getattr(self, "src_aux", False):
+                # on its own stream: the source problems of a rank are a fraction of a chip-filling grid (one frame's
+                # queries: 32..128 workgroups), so they run BESIDE the exchange and the bank attention that follows it,
+                # not in front of it; joined before the block's results leave (below)
+                src_done = self._on_aux(dev, [q3, k3, v3, out], lambda st: ops.ext_attn_views(
+                    q3, k3, v3, out, heads, scale, inject, "source", no_split=not self.attn_split, stream=st))
+            else:
+                ops.ext_attn_views(q3, k3, v3, out, heads, scale, inject, "source", no_split=not self.attn_split)
         work.wait()
         # ---- bank branches on this rank's head group, all K frames: read `recv`, write `send2`, both in place
         rp = recv.permute(1, 0, 2, 3)                                   # [ns, K, S, hd] view
@@ -335,6 +365,8 @@ class FrameShard:
         self._a2a(recv2.view(W * Kl, -1), send2.view(K, -1),
                   None if even else [Kl] * W, None if even else self.counts)
         ops.head_unpack(recv2, [out[1], out[2]])
+        if src_done is not None:
+            src_done.wait()
         return out.view(3 * Kl, S, D) if out4 is None else out4
 
     # ------------------------------------------------------------------ pivotal pass of one block, in place
@@ -479,3 +511,97 @@ class FrameShard:
         self.halo_wait(halo_reqs)
         first = self.propagate(0, tgt_all[:nS], res[:, 0].reshape(3 * n, S, D), piv_ext, inv_ext, kf_out_ext, w, n)
         return first, rest
+
+
+class _SlotWait:
+    """Pending neighbour halo of one block of a `NativeShard`: wait() orders the CURRENT stream behind it."""
+
+    def __init__(self, shard, slot, device):
+        self.shard, self.slot, self.device = shard, slot, device
+
+    def wait(self):
+        from . import _lib
+        rc = _lib.load().tf_rank_halo_wait(self.shard._rk, self.slot, torch.cuda.current_stream(self.device).cuda_stream)
+        if rc:
+            _lib.check(rc, "tf_rank_halo_wait")
+        return True
+
+
+class NativeShard(FrameShard):
+    """`FrameShard` whose pivotal pass of a block is ONE call into the library (tf_rank_pivotal, csrc/rank_exec.hip):
+    pack, exchanges, source and bank attention, unpack and the neighbour halo are issued by native code on the
+    library's own streams -- the host cost of a block drops from a dozen Python-level op calls (200-300 us at a rank of
+    8, more than the GPU needs for the block at the coarse levels) to one foreign call.  Same results as `FrameShard`
+    bit for bit (same kernels, same buffers' layouts).  `comm` / `halo_comm`: `tokenflow_amd.comm.HipComm` objects (RCCL
+    through the C ABI; a second communicator lets the halo of one block travel beside the exchanges of the next).
+    Only the in-place two-pass API (`ext_alloc`, `pivotal_block`, `propagate_all(..., halo_reqs=)`) goes native; the
+    other methods are `FrameShard`'s own on the same communicator."""
+
+    def __init__(self, K: int, comm, halo_comm=None, attn_split: Optional[bool] = None):
+        super().__init__(K, comm=comm, attn_split=attn_split)
+        from . import _lib
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        _lib.check(lib.tf_rank_create(comm._h if comm is not None else None,
+                                      halo_comm._h if halo_comm is not None else None, K, ctypes.byref(h)),
+                   "tf_rank_create")
+        self._rk, self._halo_comm = h, halo_comm
+        assert lib.tf_rank_local_keyframes(h) == self.Kl and lib.tf_rank_first_keyframe(h) == self.kf0
+        self._slot = 0
+        self._nws = {}
+
+    def close(self):
+        rk, self._rk = getattr(self, "_rk", None), None
+        if rk is not None:
+            from . import _lib
+            _lib.load().tf_rank_destroy(rk)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    def pivotal_block(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool, ext,
+                      mode: Optional[str] = None):
+        from . import _lib
+        lib = _lib.load()
+        piv, inv, kfo = ext
+        B, S, D = q_local.shape
+        Kl = self.Kl
+        o = 1 if self.world > 1 else 0
+        if mode is None:
+            mode = self.auto_mode(heads, S)
+        dt = ops._DT.get(q_local.dtype)
+        if dt is None or dt == _lib.TF_F32 or not (q_local.is_cuda and piv.is_contiguous() and inv.is_contiguous()
+                                                    and kfo.is_contiguous()):
+            raise TypeError("NativeShard.pivotal_block: 16-bit GPU tensors, contiguous halo-extended buffers")
+
+        def frames(t):     # [3*Kl, S, D] (token stride free) -> [3, Kl, S, D] view
+            if t.stride(2) != 1 or t.stride(0) != S * t.stride(1):
+                t = t.contiguous()
+            return t.view(3, Kl, S, D) if t.is_contiguous() else t.unflatten(0, (3, Kl))
+        q3, k3, v3 = frames(q_local), frames(k_local), frames(v_local)
+        if k3.stride(2) != v3.stride(2) or (mode == "heads" and q3.stride(2) != k3.stride(2)):
+            q3, k3, v3 = (t.contiguous() for t in (q3, k3, v3))
+        strides = (ctypes.c_int64 * 8)(q3.stride(0), q3.stride(1), k3.stride(0), k3.stride(1), v3.stride(0), v3.stride(1),
+                                       q3.stride(2), k3.stride(2))
+        dh = D // heads
+        key = (S, heads, dh, dt, q_local.device)
+        ws = self._nws.get(key)
+        if ws is None:
+            nbytes = lib.tf_rank_pivotal_workspace_bytes(self._rk, S, heads, dh, dt)
+            ws = self._nws[key] = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=q_local.device)
+        flags = (_lib.TF_ATTN_INJECT if inject else 0) | (0 if self.attn_split else _lib.TF_ATTN_NO_SPLIT)
+        if ops.FOLD_SCALE:
+            flags |= _lib.TF_ATTN_FOLD_SCALE
+        slot = self._slot
+        self._slot = (slot + 1) % _lib.TF_RANK_SLOTS
+        rc = lib.tf_rank_pivotal(self._rk, q3.data_ptr(), k3.data_ptr(), v3.data_ptr(), strides, piv.data_ptr(),
+                                 inv.data_ptr(), kfo.data_ptr(), S, heads, dh, float(scale), flags, dt,
+                                 _lib.TF_RANK_HEADS if mode == "heads" else _lib.TF_RANK_BANK, slot, ws.data_ptr(),
+                                 ws.numel(), torch.cuda.current_stream(q_local.device).cuda_stream)
+        if rc:
+            _lib.check(rc, "tf_rank_pivotal")
+        reqs = [_SlotWait(self, slot, q_local.device)] if self.world > 1 else []
+        return piv, inv, kfo.view(3 * (Kl + o), S, D), reqs

@@ -1,0 +1,12 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03h; mkdir -p $O
+cd $R
+timeout 1500 python -m pytest tests/test_sharded_gpu.py tests/test_fullsize_gpu.py -x -q -k "native or hooks_16bit or comm or sharded_real" > $O/tests.txt 2>&1; echo "rc=$?" >> $O/tests.txt
+cd /tmp
+timeout 300 python $R/tools/rank_step_microbench.py --reps 10 --only split,heads --native > $O/rank_step.txt 2>&1
+timeout 300 python $R/tools/rank_step_microbench.py --reps 10 --only split,heads >> $O/rank_step.txt 2>&1
+timeout 300 python $R/tools/rank_step_microbench.py --reps 10 --only onepass,heads --native >> $O/rank_step.txt 2>&1
+timeout 300 python $R/tools/rank_step_microbench.py --reps 10 --only split,auto --native >> $O/rank_step.txt 2>&1
+timeout 300 python $R/tools/rank_step_microbench.py --reps 10 --only split,bank --native >> $O/rank_step.txt 2>&1
+ls $O

@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--single-ms", type=float, default=27.9, help="single-GPU step (driver, round 2)")
     ap.add_argument("--profile", action="store_true", help="cProfile of the host side of 5 steps (first configuration)")
     ap.add_argument("--only", default="", help="e.g. 'split,auto': run one configuration (split|onepass , auto|heads|bank)")
+    ap.add_argument("--native", action="store_true",
+                    help="sharded.NativeShard: the pivotal pass of a block as ONE library call (tf_rank_pivotal) on the "
+                         "library's loopback transport (tf_comm_init_loopback: the same wire-less stand-in, in C)")
     args = ap.parse_args()
     cfg = workload.CONFIGS[args.config]
     dev = torch.device("cuda", 0)
@@ -118,14 +121,20 @@ def main():
         for mode in (None, "heads", "bank"):
             if args.only and args.only != f"{'split' if split else 'onepass'},{mode or 'auto'}":
                 continue
-            comm = LocalComm(args.rank, args.world)
-            shard = sharded.FrameShard(cfg.K, comm=comm, attn_split=split)
+            if args.native:
+                from tokenflow_amd.comm import HipComm
+                comm = HipComm.loopback(args.rank, args.world)
+                comm.bytes = 0
+                shard = sharded.NativeShard(cfg.K, comm, HipComm.loopback(args.rank, args.world), attn_split=split)
+            else:
+                comm = LocalComm(args.rank, args.world)
+                shard = sharded.FrameShard(cfg.K, comm=comm, attn_split=split)
             if mode == "heads" and any(l[2] % args.world for l in cfg.levels):
                 continue
             gen = torch.Generator(device=dev).manual_seed(1234 + args.rank)
             blocks = [bench.Block(cfg, lvl, inj, shard, gen, dev) for lvl, inj in workload.BLOCKS]
             modes = [mode or shard.auto_mode(l[2], l[0]) for l in cfg.levels]
-            print(f"=== rank {args.rank} of {args.world}, {cfg.name}: Kl={shard.Kl}, attention "
+            print(f"=== {'NATIVE executor, ' if args.native else ''}rank {args.rank} of {args.world}, {cfg.name}: Kl={shard.Kl}, attention "
                   f"{'split+merge' if split else 'one-pass (bit-exact)'}, exchange per level {modes}", flush=True)
             if args.profile:
                 import cProfile
@@ -151,8 +160,9 @@ def main():
             bench.run_step(cfg, blocks, shard, False, w, exchange=mode)
             torch.cuda.synchronize()
             wire_us = comm.bytes / (args.link_gbs * 1e3) / min(args.world - 1, 7)
-            print(f"  wire: {comm.bytes / 1e6:7.1f} MB sent per rank and step; at {args.link_gbs:.0f} GB/s per link over "
-                  f"{min(args.world - 1, 7)} links {wire_us:7.0f} us if nothing overlapped (halo: one link only)")
+            if comm.bytes:
+                print(f"  wire: {comm.bytes / 1e6:7.1f} MB sent per rank and step; at {args.link_gbs:.0f} GB/s per link over "
+                      f"{min(args.world - 1, 7)} links {wire_us:7.0f} us if nothing overlapped (halo: one link only)")
             for lvl in range(len(cfg.levels)):
                 blk = next(b for b in blocks if b.lvl == lvl)
                 for inj in ((False, True) if blk.injected or any(b.injected for b in blocks if b.lvl == lvl) else (False,)):
@@ -161,9 +171,8 @@ def main():
 
                     def pivotal():
                         scale = (b1.D // b1.h) ** -0.5
-                        halo = shard.halo_start(b1.pivots, bench.ops.pivot_inv_norm(b1.pivots))
-                        kf = shard.pivotal_attention(b1.q, b1.k, b1.v, b1.h, scale, inj, mode=mode)
-                        state["h"] = shard.halo_finish(halo, kf, wait=False)
+                        bench.ops.pivot_inv_norm(b1.pivots, out=b1.ext[1][1:])
+                        state["h"] = shard.pivotal_block(b1.q, b1.k, b1.v, b1.h, scale, inj, b1.ext, mode=mode)
 
                     def prop():
                         pe, ie, ke, reqs = state["h"]
