@@ -65,8 +65,9 @@ def parse():
     ap.add_argument("--config", default="cfg2", choices=list(workload.CONFIGS))
     ap.add_argument("--pivotal-exchange", default="auto", choices=["auto", "heads", "bank"],
                     help="N > 1: how the pivotal pass is exchanged (sharded.py); auto = heads when they divide")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo", "hip", "native"],
-                    help="N > 1: nccl (= RCCL through torch.distributed, the default); hip = the exchange steps through "
+    ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo", "hip", "native"],
+                    help="N > 1: auto (default) = native, falling back to nccl if the library's communicators cannot be "
+                         "created; nccl = RCCL through torch.distributed; hip = the exchange steps through "
                          "the library's C ABI (tf_comm_*: RCCL without torch.distributed on the data path; gloo carries "
                          "only the barrier and the unique id); native = hip plus the pivotal pass of a block as ONE library "
                          "call (tf_rank_pivotal: pack, exchanges, attention, unpack, halo issued by native code; a second "
@@ -438,7 +439,7 @@ def parity_check(cfg, blocks, w):
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: become `torch.distributed.run` with N ranks on this node."""
     n_dev = torch.cuda.device_count()
-    if args.backend in ("nccl", "hip", "native") and n_dev < args.gpus:
+    if args.backend in ("auto", "nccl", "hip", "native") and n_dev < args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible "
                  f"(use --backend gloo to let ranks share a GPU for a functional check)")
     with socket.socket() as s:
@@ -463,23 +464,31 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
     cfg = workload.CONFIGS[args.config]
     hip_comm = halo_comm = None
-    if world > 1 and args.backend in ("hip", "native"):
-        from tokenflow_amd.comm import HipComm
-        uid = [HipComm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)          # control plane only: the tensors never touch gloo
-        hip_comm = HipComm(uid[0], rank, world)
-        if args.backend == "native":                    # the halo on a communicator of its own (see rank_exec.hip)
-            uid = [HipComm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            halo_comm = HipComm(uid[0], rank, world)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.backend in ("auto", "hip", "native"):
+            dist.init_process_group("gloo")                 # control plane only: the tensors never touch gloo
+            from tokenflow_amd import comm as tfcomm
+            # hip: one communicator; native: a second one carries the halo (rank_exec.hip)
+            comms, why = tfcomm.bootstrap(rank, world, 1 if args.backend == "hip" else 2)
+            if comms is not None:
+                hip_comm, halo_comm = comms[0], (comms[1] if len(comms) > 1 else None)
+            if hip_comm is None:
+                if args.backend != "auto":
+                    sys.exit(f"bench.py: --backend {args.backend}: the library's communicator could not be created: {why}")
+                if rank == 0:
+                    print(f"[bench] native communicators unavailable ({why}); falling back to torch.distributed/nccl",
+                          file=sys.stderr, flush=True)
+                dist.destroy_process_group()
+                args.backend = "nccl"
+            elif args.backend == "auto":
+                args.backend = "native"
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        elif args.backend == "gloo":
+            dist.init_process_group("gloo")
     split = world > 1 and not args.no_attn_split
     if world > 1 and args.backend == "native":
         shard = sharded.NativeShard(cfg.K, hip_comm, halo_comm, attn_split=split)

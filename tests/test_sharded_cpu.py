@@ -220,3 +220,41 @@ def test_shard_runs():
     assert (sh.Kl, sh.kf0, sh.counts, sh.even) == (5, 0, [5], True)
     one = sharded.FrameShard.__new__(sharded.FrameShard)
     assert [K // 8 + (1 if r < K % 8 else 0) for K in (25,) for r in range(8)] == [4, 3, 3, 3, 3, 3, 3, 3]
+
+
+def _bootstrap_worker(rank, world, port, fail_rank, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tokenflow_amd import comm as tfcomm
+        closed = []
+
+        class Fake:
+            def __init__(self, uid, r, w):
+                if r == fail_rank and len(closed) == 0 and Fake.made == 1:   # the SECOND communicator fails on one rank
+                    raise RuntimeError("no device for you")
+                Fake.made += 1
+                self.rank, self.world = r, w
+
+            def close(self):
+                closed.append(self)
+        Fake.made = 0
+        comms, why = tfcomm.bootstrap(rank, world, 2, make=Fake)
+        if fail_rank < 0:
+            ret[rank] = comms is not None and len(comms) == 2 and why is None and not closed
+        else:   # every rank gets the same verdict and the reason; the first communicator, created everywhere, is closed
+            ret[rank] = comms is None and "no device for you" in why and len(closed) == 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [-1, 1])
+def test_comm_bootstrap_agrees_on_every_rank(fail_rank):
+    """bench.py's default N > 1 path creates the library's communicators through `comm.bootstrap`: all ranks come
+    back with a full set, or all come back with None and the failing rank's reason (nobody left in a collective)."""
+    world = 3
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bootstrap_worker, args=(world, port, fail_rank, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}

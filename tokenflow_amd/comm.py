@@ -164,3 +164,39 @@ class HipComm:
         re_ = (ctypes.c_int64 * max(nr, 1))(*[t.numel() for t in recv[:nr]])
         _lib.check(_lib.load().tf_sendrecv_pivot(self._h, sp, se, ns, send_peer, rp, re_, nr, recv_peer, dt,
                                                  _stream(ts[0]) if stream is None else stream), "tf_sendrecv_pivot")
+
+
+def bootstrap(rank: int, world: int, n: int = 1, group=None, make=None):
+    """Create `n` communicators on every rank of a torch.distributed group that is used as the control plane only
+    (gloo: unique ids out, one agreement flag back; no tensor of the path touches it).  Every rank returns the same
+    kind of result: (list of n communicators, None), or (None, reason) when ANY rank failed to create one -- no rank
+    is left holding half a set, and nobody blocks in a collective the others never enter.
+    make(unique_id, rank, world) -> communicator; default `HipComm` (RCCL through the C ABI)."""
+    import torch.distributed as dist
+    make = make or HipComm
+    comms, why = [], None
+    for _ in range(n):
+        uid, err = [None], None
+        if rank == 0:
+            try:
+                uid[0] = HipComm.unique_id() if make is HipComm else b"\0" * 128
+            except Exception as e:  # noqa: BLE001  (RCCL not loadable ...)
+                err = str(e)
+        dist.broadcast_object_list(uid, src=0, group=group)
+        c = None
+        if uid[0] is not None:
+            try:
+                c = make(uid[0], rank, world)
+            except Exception as e:  # noqa: BLE001
+                err = str(e)
+        flag = torch.tensor([1 if c is not None else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)       # every rank takes the same branch
+        if not int(flag.item()):
+            reasons = [None] * world
+            dist.all_gather_object(reasons, err, group=group)
+            why = next((r for r in reasons if r), "a rank failed to create its communicator")
+            for x in comms + ([c] if c is not None else []):
+                x.close()
+            return None, why
+        comms.append(c)
+    return comms, None
