@@ -242,8 +242,8 @@ def _bootstrap_worker(rank, world, port, fail_rank, ret):
         comms, why = tfcomm.bootstrap(rank, world, 2, make=Fake)
         if fail_rank < 0:
             ret[rank] = comms is not None and len(comms) == 2 and why is None and not closed
-        else:   # every rank gets the same verdict and the reason; the first communicator, created everywhere, is closed
-            ret[rank] = comms is None and "no device for you" in why and len(closed) == 1
+        else:   # every rank gets the same verdict and the reason; whatever a rank had created is closed again
+            ret[rank] = comms is None and "no device for you" in why and len(closed) == (1 if rank == fail_rank else 2)
     finally:
         dist.destroy_process_group()
 
