@@ -471,10 +471,10 @@ def main():
         if args.backend in ("auto", "hip", "native"):
             dist.init_process_group("gloo")                 # control plane only: the tensors never touch gloo
             from tokenflow_amd import comm as tfcomm
-            # hip: one communicator; native: a second one carries the halo (rank_exec.hip)
-            comms, why = tfcomm.bootstrap(rank, world, 1 if args.backend == "hip" else 2)
+            # two communicators: the second one carries the neighbour halo (sharded.py / rank_exec.hip)
+            comms, why = tfcomm.bootstrap(rank, world, 2)
             if comms is not None:
-                hip_comm, halo_comm = comms[0], (comms[1] if len(comms) > 1 else None)
+                hip_comm, halo_comm = comms
             if hip_comm is None:
                 if args.backend != "auto":
                     sys.exit(f"bench.py: --backend {args.backend}: the library's communicator could not be created: {why}")
@@ -485,15 +485,19 @@ def main():
                 args.backend = "nccl"
             elif args.backend == "auto":
                 args.backend = "native"
+        halo_group = None
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
+            halo_group = dist.new_group(backend="nccl")      # a second RCCL communicator for the neighbour halo
         elif args.backend == "gloo":
             dist.init_process_group("gloo")
     split = world > 1 and not args.no_attn_split
     if world > 1 and args.backend == "native":
         shard = sharded.NativeShard(cfg.K, hip_comm, halo_comm, attn_split=split)
+    elif world > 1:
+        shard = sharded.FrameShard(cfg.K, comm=hip_comm, attn_split=split, halo_comm=halo_comm, halo_group=halo_group)
     else:
-        shard = sharded.FrameShard(cfg.K, comm=hip_comm, attn_split=split)
+        shard = sharded.FrameShard(cfg.K, attn_split=False)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     blocks = [Block(cfg, lvl, inj, shard, gen, dev) for lvl, inj in workload.BLOCKS]
     w = blend_w(cfg.chunk, dev)

@@ -109,7 +109,7 @@ class FrameShard:
     (cfg5's 25 chunks over 8 ranks -> 4,3,3,3,3,3,3,3)."""
 
     def __init__(self, K: int, group: Optional[dist.ProcessGroup] = None, comm=None,
-                 attn_split: Optional[bool] = None):
+                 attn_split: Optional[bool] = None, halo_group: Optional[dist.ProcessGroup] = None, halo_comm=None):
         # attn_split: let the attention split a rank's small grid over extra workgroups and merge (faster: -15..40 %
         # on a rank's attention at 8 GPUs, DESIGN.md 4.1; results then agree with the single-GPU ones within the
         # output rounding).  Default False: one pass per bank problem, arithmetic independent of the grid, sharded
@@ -124,6 +124,11 @@ class FrameShard:
         self.group = group
         self.comm = comm                       # tokenflow_amd.comm.HipComm: exchanges through the C ABI instead
         self._cs = None                        # its side stream
+        # The neighbour halo on a communicator (and side stream) of its own: collectives of ONE RCCL communicator run
+        # in issue order, so on the pivotal pass's communicator the ~10 MB halo message of block b (one xGMI link) would
+        # sit in front of block b+1's first all-to-all.  None = share the pivotal pass's.
+        self.halo_group, self.halo_comm = halo_group, halo_comm
+        self._hs = None
         if comm is not None:
             self.world, self.rank = comm.world, comm.rank
         else:
@@ -152,7 +157,7 @@ class FrameShard:
             t = b[key] = torch.empty(shape, dtype=dtype, device=device)
         return t
 
-    def _side(self, tensors, fn):
+    def _side(self, tensors, fn, halo: bool = False):
         """HipComm path: run `fn(stream)` (RCCL calls through the C ABI, asynchronous on the stream they are handed)
         on the exchange stream, ordered after everything already enqueued on the compute stream; returns the handle
         to wait on.  No stream context manager and no device-less torch.cuda query on this path: both cost tens of
@@ -165,14 +170,19 @@ class FrameShard:
         if getattr(self, "_cs", None) is None:
             self._cs = torch.cuda.Stream(device=dev)
             self._ring = _EventRing()
+        side = self._cs
+        if halo and getattr(self, "halo_comm", None) is not None:
+            if getattr(self, "_hs", None) is None:
+                self._hs = torch.cuda.Stream(device=dev)
+            side = self._hs
         e = self._ring.next()
         e.record(cur)
-        self._cs.wait_event(e)
-        fn(self._cs.cuda_stream)
+        side.wait_event(e)
+        fn(side.cuda_stream)
         for t in tensors:
-            t.record_stream(self._cs)          # allocator: not reusable before the exchange stream is done with it
+            t.record_stream(side)              # allocator: not reusable before the exchange stream is done with it
         done = self._ring.next()
-        done.record(self._cs)
+        done.record(side)
         return _StreamWork(done, dev)
 
     def _on_aux(self, dev, tensors, fn):
@@ -452,7 +462,7 @@ class FrameShard:
 
     def _p2p(self, send_tensors, recv_tensors):
         """One grouped point-to-point exchange: `send_tensors` to rank r+1, `recv_tensors` from rank r-1."""
-        comm = getattr(self, "comm", None)
+        comm = getattr(self, "halo_comm", None) or getattr(self, "comm", None)
         if comm is not None:
             to = self.rank + 1 if self.rank + 1 < self.world else -1
             frm = self.rank - 1 if self.rank > 0 else -1
@@ -464,14 +474,15 @@ class FrameShard:
                 for dt in dict.fromkeys(t.dtype for t in list(send_tensors) + list(recv_tensors)):
                     comm.sendrecv([t for t in send_tensors if t.dtype == dt], to,
                                   [t for t in recv_tensors if t.dtype == dt], frm, stream=st)
-            return [self._side(list(send_tensors) + list(recv_tensors), go)]
+            return [self._side(list(send_tensors) + list(recv_tensors), go, halo=True)]
         opsl = []
+        grp = getattr(self, "halo_group", None) or self.group
         if self.rank + 1 < self.world:
             peer = self._peer(self.rank + 1)
-            opsl += [dist.P2POp(dist.isend, t, peer, self.group) for t in send_tensors]
+            opsl += [dist.P2POp(dist.isend, t, peer, grp) for t in send_tensors]
         if self.rank > 0:
             peer = self._peer(self.rank - 1)
-            opsl += [dist.P2POp(dist.irecv, t, peer, self.group) for t in recv_tensors]
+            opsl += [dist.P2POp(dist.irecv, t, peer, grp) for t in recv_tensors]
         return dist.batch_isend_irecv(opsl) if opsl else []
 
     def _peer(self, group_rank: int) -> int:
