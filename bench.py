@@ -453,6 +453,8 @@ def self_launch(args):
 
 def main():
     args = parse()
+    # before the HIP runtime initialises: the host driver of this pool only supports dmabuf IPC (RCCL between processes)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
