@@ -379,7 +379,7 @@ def parity_check(cfg, blocks, w):
     are the worst over the levels; `by_level` keeps each."""
     from oracle import tokenflow_oracle as orc
     by_level, attn_rows, nn_total = [], 0, 0
-    worst_state, worst_state32 = {}, {}
+    worst_state, worst_state32, worst_ratio = {}, {}, [0.0]
     nn_bad = nn_diff = 0
     K, n = cfg.K, cfg.chunk
     for lvl in range(len(cfg.levels)):
@@ -391,12 +391,12 @@ def parity_check(cfg, blocks, w):
         d = D // h
         qc, kc, vc = (t.float().cpu().view(3, K, S, h, d) for t in (blk.q, blk.k, blk.v))
         rows = torch.arange(min(3, S - 1), S, max(S // 24, 1))
-        worst, worst32, floor16 = {}, {}, 0.0
+        worst, worst32, floor16, lvl_ratio = {}, {}, 0.0, 0.0
         for inject in ((False, True) if cfg.pnp else (False,)):
             out = ops.ext_attn(blk.q, blk.k, blk.v, h, d ** -0.5, inject).float().cpu().view(3, K, S, h, d)
             # the same launch with TF_ATTN_OUT_F32: the normalised fp32 accumulator, no 16-bit output rounding
             out32 = ops.ext_attn(blk.q, blk.k, blk.v, h, d ** -0.5, inject, out_dtype=torch.float32).cpu().view(3, K, S, h, d)
-            err = err32 = 0.0
+            err = err32 = ratio = 0.0
             for b, f, head in [(0, 0, 0), (0, K - 1, h - 1), (1, 0, h // 2), (1, K - 1, 0), (2, K // 2, h - 1), (2, K - 2, 1)]:
                 bq = 0 if (inject and b > 0) else b
                 qr = qc[bq, f, rows, head]
@@ -404,15 +404,22 @@ def parity_check(cfg, blocks, w):
                     kk, vv = kc[0, f, :, head], vc[0, f, :, head]
                 else:
                     kk, vv = kc[bq, :, :, head].reshape(K * S, d), vc[b, :, :, head].reshape(K * S, d)
-                ref = torch.softmax(qr @ kk.T * d ** -0.5, dim=-1) @ vv          # tokenflow_utils.py:173-179
-                err = max(err, float((out[b, f, rows, head] - ref).abs().max()))
+                pm = torch.softmax(qr @ kk.T * d ** -0.5, dim=-1)
+                ref = pm @ vv                                                    # tokenflow_utils.py:173-179
+                e16 = (out[b, f, rows, head] - ref).abs()
+                err = max(err, float(e16.max()))
                 err32 = max(err32, float((out32[b, f, rows, head] - ref).abs().max()))
+                # the bound the parity tests assert for 16-bit P and output (tests/test_kernels_gpu.py)
+                bound = 2e-4 + 2.0 ** -8 * (ref.abs() + pm @ vv.abs())
+                ratio = max(ratio, float((e16 / bound).max()))
                 # what ANY bf16 tensor holding `ref` is off by at worst: half an ulp = 2^(exponent - 8)
                 floor16 = max(floor16, float(torch.exp2(torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 8).max()))
             state = "inject" if inject else "plain"
             worst[state], worst32[state] = err, err32
             worst_state[state] = max(worst_state.get(state, 0.0), err)
             worst_state32[state] = max(worst_state32.get(state, 0.0), err32)
+            worst_ratio[0] = max(worst_ratio[0], ratio)
+            lvl_ratio = max(lvl_ratio, ratio)
             attn_rows += int(len(rows)) * 6
         # NN search of chunk c on sampled targets
         c = min(3, K - 1)
@@ -434,16 +441,21 @@ def parity_check(cfg, blocks, w):
         by_level.append({"level": lvl, "S": S, "D": D, "head_dim": d,
                          "attn_linf": {k: round(v, 6) for k, v in worst.items()},
                          "attn_linf_fp32_out": {k: round(v, 6) for k, v in worst32.items()},
+                         "attn_err_over_bf16_bound": round(lvl_ratio, 4),
                          "bf16_half_ulp_of_largest_ref": round(floor16, 6),
                          "nn_mismatch_rate": n_bad / total, "nn_index_diff_rate": n_diff / total})
     return {"attn_linf": round(max(worst_state.values()), 6),
             "attn_linf_by_state": {k: round(v, 6) for k, v in worst_state.items()},
             "attn_linf_fp32_out": round(max(worst_state32.values()), 6),
+            "attn_err_over_bf16_bound": round(worst_ratio[0], 4),
             "attn_rows_checked": attn_rows, "tolerance": 1e-3,
-            "tolerance_note": "1e-3 is met by the kernel's arithmetic at every level (attn_linf_fp32_out: the same "
-                              "launch with TF_ATTN_OUT_F32); a bf16 OUTPUT adds its own rounding, up to half an ulp = "
-                              "2^-9 relative (by_level[].bf16_half_ulp_of_largest_ref): on these N(0,1) inputs the "
-                              "short-bank problems of the coarse levels reach |out| > 0.25, where that alone exceeds 1e-3",
+            "tolerance_note": "attn_linf is absolute.  With P and the output in bf16 (8 significand bits; the reference's "
+                              "autocast rounds at the same two points in its 16-bit type) the deviation is relative: "
+                              "bound = 2e-4 + 2^-8 (|ref| + softmax.|V|), the one the parity tests assert; "
+                              "attn_err_over_bf16_bound <= 1 means inside it.  In absolute terms 1e-3 holds where "
+                              "|out| <= 0.25: at the fine levels (thousands of keys averaged); the short source-branch "
+                              "problems of the coarse levels reach |out| ~ 0.6 on these N(0,1) inputs.  "
+                              "attn_linf_fp32_out = the same launches with TF_ATTN_OUT_F32 (no output rounding)",
             "nn_mismatch_rate": nn_bad / nn_total, "nn_index_diff_rate": nn_diff / nn_total,
             "nn_targets_checked": nn_total, "by_level": by_level,
             "reference": "oracle (fp32 CPU restatement pinned to the verbatim reference, tests/golden/)"}

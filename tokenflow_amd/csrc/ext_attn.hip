@@ -1180,11 +1180,20 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     typedef typename T::vec8 vec8;
     typedef typename T::vec4 vec4;
     constexpr int NT = 64 * NW;
-    constexpr int NPK = C::npk(NT), NPV = C::npv(NT);
-    constexpr int BUF_ELEMS = C::K_ELEMS + C::V_ELEMS;
-    constexpr bool ONES = (DH % 32) != 0;   // denominator from the MFMA (row DH of the V^T image = 1.0)
-    constexpr int ONES_R = ((DH % 32) & 3) + 4 * ((DH % 32) >> 3);
-    static_assert(!ONES || ((DH % 32) & 4) == 0, "row DH must live in lane half 0");
+    // MODE_DUAL (q/k injection, Dh = 40): uncond and cond share q, k, the scores and P; the two banks' V^T rows are
+    // packed into ONE LDS image of 3 M-tiles (rows 0-39 uncond, 40-79 cond, row 80 the common ones row) exactly as in
+    // ext_attn_kernel's PACK form, so the only differences to the single-bank kernel are the number of staged V^T rows
+    // (VR), the number of P.V M-tiles (MT) and the epilogue's row -> (bank, feature) decode.
+    constexpr bool PACK = MODE == MODE_DUAL;
+    static_assert(!PACK || DH == 40, "the packed dual-V image is a Dh = 40 form");
+    constexpr int VR = PACK ? 2 * DH : DH;              // staged V^T rows per tile
+    constexpr int MT = PACK ? 3 : C::MT;                // P.V M-tiles
+    constexpr int V_ELEMS = MT * 32 * C::VROW;
+    constexpr int NPK = C::npk(NT), NPV = (VR * 8 + NT - 1) / NT;
+    constexpr int BUF_ELEMS = C::K_ELEMS + V_ELEMS;
+    constexpr bool ONES = (VR % 32) != 0;   // denominator from the MFMA (row VR of the V^T image = 1.0)
+    constexpr int ONES_R = ((VR % 32) & 3) + 4 * ((VR % 32) >> 3);
+    static_assert(!ONES || ((VR % 32) & 4) == 0, "the ones row must live in lane half 0");
     constexpr bool BOUND = DH == 40;        // needs the key norms of the pre-pass
     constexpr float BOUND_T = std::is_same<E, _Float16>::value ? 14.0f : 60.0f;
 
@@ -1215,6 +1224,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
             u -= nbank;
             b = 0;
         }
+    } else if constexpr (MODE == MODE_DUAL) {
+        b = 1;
+        seg = u % nseg;
+        u /= nseg;
     } else {
         b = 0;
     }
@@ -1236,7 +1249,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     for (int id = tid; id < 2 * BUF_ELEMS / 8; id += NT) st16(reinterpret_cast<E*>(smem) + id * 8, u32x4{0, 0, 0, 0});
     __syncthreads();
     if constexpr (ONES)
-        for (int id = tid; id < 2 * 64; id += NT) sV(id >> 6)[DH * C::VROW + (id & 63)] = (E)1.f;
+        for (int id = tid; id < 2 * 64; id += NT) sV(id >> 6)[VR * C::VROW + (id & 63)] = (E)1.f;
 
     // ---- Q fragments
     const int q_row = qt * (32 * NW) + wave * 32 + l31;
@@ -1280,9 +1293,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     }
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
-        const int id = min(tid + NT * i, DH * 8 - 1);
-        v_goff[i] = (id >> 3) * (int)vt_row + (id & 7) * 8;
-        v_loff[i] = (id >> 3) * C::VROW + (id & 7) * 8;
+        const int id = min(tid + NT * i, VR * 8 - 1);
+        const int row = id >> 3;   // image row: bank row / DH (the next branch's rows lie H*DH image rows further), feature row % DH
+        v_goff[i] = ((row / DH) * H * DH + row % DH) * (int)vt_row + (id & 7) * 8;
+        v_loff[i] = row * C::VROW + (id & 7) * 8;
     }
     const int v_wrap = p.Spad - (tpf - 1) * 64;
     const int64_t k_wrap_off = p.k_fs - (int64_t)(tpf - 1) * 64 * p.ld;
@@ -1311,15 +1325,15 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     auto write_v = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NPV; ++i)
-            if (tid + NT * i < DH * 8) st16(sV(buf) + v_loff[i], rv[i]);
+            if (tid + NT * i < VR * 8) st16(sV(buf) + v_loff[i], rv[i]);
     };
 
-    f32x16 o[C::MT], s[2];
+    f32x16 o[MT], s[2];
     vec8 pf[2][2];      // P of the two 32-key halves, two 16-key k-steps each
     float m_run = -INFINITY;   // BOUND: deferred shift; else the running maximum (raw-score units)
     float l_run = 0.f;         // !ONES: this lane's share of the denominator
 #pragma unroll
-    for (int mt = 0; mt < C::MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[mt][r] = 0.f;
 #pragma unroll
@@ -1365,7 +1379,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     };
     auto rescale = [&](float alpha) {
 #pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
     };
@@ -1388,7 +1402,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
         constexpr int Hh = decltype(h_c)::value;
         constexpr int X = 1 - Hh;
         constexpr bool NEXT = decltype(next_c)::value, SM = decltype(sm_c)::value;
-        constexpr IlSchedule<C::MT, C::KS, NEXT> sch{};
+        constexpr IlSchedule<MT, C::KS, NEXT> sch{};
         constexpr int NM = sch.N;
         bool move = false;
         float alpha = 1.f, lsum = 0.f;
@@ -1495,7 +1509,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     // ---- epilogue
     float l_tot;
     if constexpr (ONES)
-        l_tot = __shfl(o[C::MT - 1][ONES_R], l31);   // row DH of the V^T image is 1.0: sum of P from the MFMA
+        l_tot = __shfl(o[MT - 1][ONES_R], l31);   // row VR of the V^T image is 1.0: sum of P from the MFMA
     else
         l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv_l = 1.0f / l_tot;
@@ -1503,37 +1517,44 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
         // split form: unnormalised O, denominator and shift (log2 domain) of this run of frames for attn_merge_kernel
         if (q_ok) {
             constexpr int PS = DH + 8;
-            const int64_t R = (((int64_t)(b - 1) * Kq + f) * H + h) * S + q_row;
-            float* row = p.partials + (R * nseg + seg) * PS;
+            auto row_ptr = [&](int vb) {
+                const int64_t R = (((int64_t)(b - 1 + vb) * Kq + f) * H + h) * S + q_row;
+                return p.partials + (R * nseg + seg) * PS;
+            };
 #pragma unroll
-            for (int mt = 0; mt < C::MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
-                    const int d0 = mt * 32 + 8 * rg + 4 * hi;
-                    if (d0 < DH) {
+                    const int r0 = mt * 32 + 8 * rg + 4 * hi;   // image row of this group of 4 (never straddles a bank)
+                    if (r0 < VR) {
+                        const int vb = r0 / DH;
                         f32x4 w;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) w[i] = o[mt][rg * 4 + i];
-                        *reinterpret_cast<f32x4*>(row + d0) = w;
+                        *reinterpret_cast<f32x4*>(row_ptr(vb) + (r0 - vb * DH)) = w;
                     }
                 }
             if (hi == 0) {
-                row[DH] = l_tot;
-                row[DH + 1] = m_run * c;
+#pragma unroll
+                for (int vb = 0; vb < (PACK ? 2 : 1); ++vb) {
+                    row_ptr(vb)[DH] = l_tot;
+                    row_ptr(vb)[DH + 1] = m_run * c;
+                }
             }
         }
     } else if (q_ok) {
         const int64_t op = b * p.o_bs + f * p.o_fs + (int64_t)q_row * (H * DH) + h * DH;
 #pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const int d0 = mt * 32 + 8 * rg + 4 * hi;
-                if (d0 < DH) {
+                const int r0 = mt * 32 + 8 * rg + 4 * hi;
+                if (r0 < VR) {
+                    const int vb = r0 / DH;
                     f32x4 w;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) w[i] = o[mt][rg * 4 + i] * inv_l;
-                    store_out4<E, vec4>(p.out, op + d0, w, p.out_f32);
+                    store_out4<E, vec4>(p.out, op + vb * p.o_bs + (r0 - vb * DH), w, p.out_f32);
                 }
             }
     }
@@ -1542,14 +1563,16 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
 template <typename T, int DH, int NW, int MODE, int MINW>
 int launch_il(AttnParams p, hipStream_t st) {
     typedef AttnCfg<DH, 64> C;
-    constexpr size_t lds = C::lds_bytes(1);
+    constexpr size_t lds = MODE == MODE_DUAL ? 2 * (size_t)(C::K_ELEMS + 96 * C::VROW) * 2   // packed dual-V image
+                                             : C::lds_bytes(1);
     auto kern = ext_attn_il_kernel<T, DH, NW, MODE, MINW>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     p.nQT = (p.S + 32 * NW - 1) / (32 * NW);
     const int per_branch = p.Kq * p.nQT * p.H;
-    const unsigned grid = (unsigned)(MODE == MODE_ALL ? (2 * p.nseg + (p.part == TF_ATTN_BANK_ONLY ? 0 : 1)) * per_branch
-                                                      : per_branch);
+    const unsigned grid = (unsigned)(MODE == MODE_ALL    ? (2 * p.nseg + (p.part == TF_ATTN_BANK_ONLY ? 0 : 1)) * per_branch
+                                     : MODE == MODE_DUAL ? p.nseg * per_branch
+                                                         : per_branch);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, p);
     TF_LAUNCH_CHECK("tf_ext_attn_fwd");
     return 0;
@@ -1652,7 +1675,12 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
             return compose([&] { return il    ? launch_il<T, 40, 8, MODE_ALL, 4>(p, st)
                                         : big ? launch_one<T, DH, 1, 8, MODE_ALL, 2, false>(p, st)
                                               : launch_one<T, DH, 1, 4, MODE_ALL, 2, false>(p, st); },
-                           [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 3, false>(p, st); },
+                           [&] {
+#ifndef TF_TUNE_NO_IL40_DUAL
+                               if (p.S >= 256 && p.S % 64 == 0) return launch_il<T, 40, 4, MODE_DUAL, 3>(p, st);
+#endif
+                               return launch_one<T, DH, 1, 4, MODE_DUAL, 3, false>(p, st);
+                           },
                            [&] { return il    ? launch_il<T, 40, 8, MODE_SOURCE, 4>(p, st)
                                         : big ? launch_one<T, DH, 1, 8, MODE_SOURCE, 2, false>(p, st)
                                               : launch_one<T, DH, 1, 4, MODE_SOURCE, 2, false>(p, st); });
