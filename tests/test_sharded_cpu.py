@@ -258,3 +258,100 @@ def test_comm_bootstrap_agrees_on_every_rank(fail_rank):
     ret = mgr.dict()
     mp.spawn(_bootstrap_worker, args=(world, port, fail_rank, ret), nprocs=world, join=True)
     assert dict(ret) == {r: True for r in range(world)}
+
+
+def _hooks_worker(rank, world, port, K, inject_t, mode, one_pass_chunks, ret):
+    """The drop-in hook layer sharded over `world` processes (register_frame_shard) against the same hooks in one
+    process: every rank runs the pivotal pass on ITS keyframes and the chunk passes of ITS chunks."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import tokenflow_utils as tfu
+        from oracle import golden_cases as gc
+        from tests import fake_diffusers as fd
+        from tests.fake_ops import FakeOps
+        from tokenflow_amd import hooks, sharded
+        fake = FakeOps()
+        hooks.ops = fake
+        sharded.ops = fake
+        cfg = gc.BLOCKS_CFG
+
+        def pipe():
+            torch.manual_seed(cfg["seed"])
+            p = fd.FakePipeline(dims=cfg["dims"], heads=cfg["heads"], cross_dim=cfg["cross_dim"]).eval()
+            tfu.register_extended_attention_pnp(p, [1])
+            tfu.set_tokenflow(p.unet)
+            tfu.register_time(p, inject_t)
+            return p
+        n, S = 2, 12
+        g = torch.Generator().manual_seed(11)
+        ok = True
+        for lvl, blk_of in ((0, lambda p: p.unet.up_blocks[3].attentions[1].transformer_blocks[0]),
+                            (1, lambda p: p.unet.down_blocks[1].attentions[0].transformer_blocks[0])):
+            D = cfg["dims"][lvl]
+            x_piv = torch.randn(3, K, S, D, generator=g)
+            enc = torch.randn(3, K, 7, cfg["cross_dim"], generator=g)
+            chunks = [torch.randn(3 * n, S, D, generator=g) for _ in range(K)]
+            enc_n = torch.randn(3 * n, 7, cfg["cross_dim"], generator=g)
+            with torch.no_grad():
+                # ---- one process: all K keyframes, all K chunks
+                ref_p = pipe()
+                blk = blk_of(ref_p)
+                tfu.register_pivotal(ref_p, True)
+                piv_out = blk(x_piv.reshape(3 * K, S, D), encoder_hidden_states=enc.reshape(3 * K, 7, -1)).view(3, K, S, D)
+                tfu.register_pivotal(ref_p, False)
+                want = []
+                for c in range(K):
+                    tfu.register_batch_idx(ref_p, c)
+                    want.append(blk(chunks[c], encoder_hidden_states=enc_n))
+                # ---- this rank: its keyframes, its chunks
+                sh = sharded.FrameShard(K)
+                my_p = pipe()
+                tfu.register_frame_shard(my_p, sh)
+                blk = blk_of(my_p)
+                lo, hi = sh.kf0, sh.kf0 + sh.Kl
+                tfu.register_pivotal(my_p, True)
+                if mode is not None:
+                    sh.auto_mode = lambda heads, S_: mode
+                got_p = blk(x_piv[:, lo:hi].reshape(3 * sh.Kl, S, D),
+                            encoder_hidden_states=enc[:, lo:hi].reshape(3 * sh.Kl, 7, -1)).view(3, sh.Kl, S, D)
+                ok = ok and torch.equal(got_p, piv_out[:, lo:hi])
+                tfu.register_pivotal(my_p, False)
+                if one_pass_chunks and sh.Kl > 1:      # the rank's chunks in ONE pass (batch_idx = a run)
+                    tfu.register_batch_idx(my_p, range(lo, hi))
+                    x_all = torch.stack([chunks[c].view(3, n, S, D) for c in range(lo, hi)], dim=1).reshape(-1, S, D)
+                    e_all = enc_n.view(3, n, 7, -1).repeat(1, sh.Kl, 1, 1).reshape(3 * sh.Kl * n, 7, -1)
+                    got = blk(x_all, encoder_hidden_states=e_all).view(3, sh.Kl, n, S, D)
+                    for j, c in enumerate(range(lo, hi)):
+                        ok = ok and torch.allclose(got[:, j].reshape(3 * n, S, D).float(), want[c].float(), atol=1e-6, rtol=0)
+                else:
+                    for c in range(lo, hi):
+                        tfu.register_batch_idx(my_p, c)
+                        ok = ok and torch.equal(blk(chunks[c], encoder_hidden_states=enc_n), want[c])
+                # a chunk of another rank is refused, not silently matched against the wrong keyframes
+                other = (hi % K) if world > 1 else None
+                if other is not None and not (lo <= other < hi):
+                    tfu.register_batch_idx(my_p, other)
+                    try:
+                        blk(chunks[other], encoder_hidden_states=enc_n)
+                        ok = False
+                    except ValueError:
+                        pass
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,K,inject_t,mode,one_pass", [(2, 4, 1, None, False), (2, 5, 0, "bank", False),
+                                                            (2, 4, 0, "heads", True), (4, 4, 1, None, False)])
+def test_hooks_sharded_equal_single_process(world, K, inject_t, mode, one_pass):
+    """`register_frame_shard`: the reference's hook API with the keyframes and chunks sharded over ranks -- pivotal
+    pass on the local keyframes (extended attention through the exchange, halo to the right neighbour), chunk passes
+    with GLOBAL chunk indices reading keyframes c and c-1 from the halo-extended caches -- equals the one-process
+    hooks bit for bit, with and without q/k injection (t = 1 is on the schedule), even and uneven runs, one keyframe
+    per rank (world 4), per-chunk and one-pass chunk order."""
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_hooks_worker, args=(world, port, K, inject_t, mode, one_pass, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}

@@ -400,3 +400,81 @@ def test_native_rank_executor_single_rank_and_loopback():
         assert torch.equal(ke.view(3, 2, S, D)[0, 1], want[0])
         sh.close()
         comm.close()
+
+
+def _hooks_gpu_worker(rank, world, port, K, inject, native, ret):
+    """The drop-in hooks sharded over ranks (register_frame_shard) with the REAL kernels under autocast: each rank's
+    block outputs equal the one-process hooks' bit for bit."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import tokenflow_utils as tfu
+        from tests import fake_diffusers as fd
+        from tokenflow_amd import hooks, ops, sharded
+        ops.NO_SPLIT = True      # the one-process reference of this toy size in its one-pass form (see _worker)
+        n, S, D, h = 2, 192, 320, 8
+
+        def make():
+            torch.manual_seed(0)
+            blk = fd.BasicTransformerBlock(D, h, cross_dim=32).eval()
+            holder = torch.nn.Module()
+            holder.unet = torch.nn.Module()
+            holder.unet.blk = blk
+            holder.cuda().bfloat16()
+            blk.attn1.forward = hooks._make_sa_forward(blk.attn1, pnp=True)
+            hooks._set_schedule(blk.attn1, [5])
+            blk.attn1.t = 5 if inject else 7
+            tfu.set_tokenflow(holder)
+            return holder, blk
+        g = torch.Generator().manual_seed(1)
+        x_piv = torch.randn(3, K, S, D, generator=g).cuda().bfloat16()
+        enc = torch.randn(3, K, 7, 32, generator=g).cuda().bfloat16()
+        enc_n = torch.randn(3 * n, 7, 32, generator=g).cuda().bfloat16()
+        chunks = []
+        for c in range(K):
+            perm = torch.randperm(S, generator=g)
+            src = x_piv[0, c][perm][None].repeat(n, 1, 1)
+            chunks.append(torch.cat([src, torch.randn(2 * n, S, D, generator=g).cuda().bfloat16()]))
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            holder, blk = make()
+            tfu.register_pivotal(holder, True)
+            piv_out = blk(x_piv.reshape(3 * K, S, D), encoder_hidden_states=enc.reshape(3 * K, 7, 32)).view(3, K, S, D)
+            tfu.register_pivotal(holder, False)
+            want = []
+            for c in range(K):
+                tfu.register_batch_idx(holder, c)
+                want.append(blk(chunks[c], encoder_hidden_states=enc_n))
+            if native:
+                from tests.gloo_transport import gloo_comm
+                sh = sharded.NativeShard(K, gloo_comm(rank, world))
+            else:
+                sh = sharded.FrameShard(K)
+            holder, blk = make()
+            tfu.register_frame_shard(holder, sh)
+            lo, hi = sh.kf0, sh.kf0 + sh.Kl
+            tfu.register_pivotal(holder, True)
+            got_p = blk(x_piv[:, lo:hi].reshape(3 * sh.Kl, S, D),
+                        encoder_hidden_states=enc[:, lo:hi].reshape(3 * sh.Kl, 7, 32)).view(3, sh.Kl, S, D)
+            ok = torch.equal(got_p, piv_out[:, lo:hi])
+            tfu.register_pivotal(holder, False)
+            for c in range(lo, hi):
+                tfu.register_batch_idx(holder, c)
+                ok = ok and torch.equal(blk(chunks[c], encoder_hidden_states=enc_n), want[c])
+        torch.cuda.synchronize()
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("K,inject,native", [(4, False, False), (5, True, False), (4, True, True)])
+def test_hooks_sharded_real_kernels_two_ranks(K, inject, native):
+    """`register_frame_shard` through the real kernels: 2 ranks sharing one GPU run the hook layer on their own
+    keyframes and chunks (fused norm, fused QKV slabs read in place by the exchange, extended attention over the
+    bank of all keyframes, propagation from the halo-extended caches); outputs equal the one-process hooks' bit for
+    bit.  native: the same on `NativeShard` (its Python-level methods on the library's host transport)."""
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_hooks_gpu_worker, args=(2, port, K, inject, native, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: True, 1: True}

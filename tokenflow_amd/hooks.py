@@ -38,6 +38,7 @@ __all__ = [
     "register_pivotal", "register_batch_idx", "register_time", "load_source_latents_t",
     "register_conv_injection", "register_extended_attention_pnp", "register_extended_attention",
     "make_tokenflow_attention_block", "set_tokenflow", "isinstance_str", "batch_cosine_sim",
+    "register_frame_shard",
 ]
 
 
@@ -76,6 +77,30 @@ def register_batch_idx(diffusion_model, batch_idx):
     """tokenflow_utils.py:13-17."""
     for module in _tokenflow_blocks(diffusion_model):
         setattr(module, "batch_idx", batch_idx)
+
+
+def register_frame_shard(diffusion_model, shard):
+    """Multi-GPU extension (no counterpart in the single-process reference): one process per GPU, each running the
+    SAME driver on ITS run of chunks.  `shard` = `tokenflow_amd.sharded.FrameShard` / `NativeShard` (rank r owns the
+    keyframes and chunks shard.kf0 .. shard.kf0 + shard.Kl - 1), or None to go back to one process.  With a shard set:
+      * the pivotal pass carries the rank's LOCAL keyframes only ([3*Kl, S, D] per block); `attn1` attends to all K
+        keyframes through `shard.pivotal_attention` (frames<->heads all-to-all or the bank all-gather), and the block
+        hands its last keyframe's pivots / inverse norms / attention output to rank r+1 (the pivots' half is issued
+        before the attention and travels under it);
+      * the chunk passes name GLOBAL chunk indices (`register_batch_idx(model, c)`, c owned by this rank; a run of the
+        rank's chunks for the one-pass form) and read keyframes c and c-1 (tokenflow_utils.py:331-333) from the
+        rank's halo-extended caches, the first one waiting for the neighbour's message.
+    Results equal the single-process hooks' bit for bit (`FrameShard`'s default one-pass attention); every rank must
+    draw the same `pivotal_idx` (run_tokenflow_pnp.py:224).  INTEGRATION.md section 3 shows the driver side."""
+    for module in _tokenflow_blocks(diffusion_model):
+        module.__dict__["_tf_shard"] = shard
+        module.__dict__.pop("_tf_halo", None)
+        module.attn1.__dict__["_tf_shard"] = shard
+
+
+def _active_shard(module):
+    shard = module.__dict__.get("_tf_shard")
+    return shard if shard is not None and shard.world > 1 else None
 
 
 _DOWN = {0: [0, 1], 1: [0, 1], 2: [0, 1]}
@@ -290,7 +315,11 @@ def _make_sa_forward(self, pnp: bool):
             if proj_dtype != cdt:
                 q, k, v = q.to(cdt), k.to(cdt), v.to(cdt)
         inject = pnp and _injecting(self)
-        out = ops.ext_attn(q, k, v, self.heads, self.scale, inject)
+        shard = None if is_cross else _active_shard(self)
+        if shard is not None:     # q, k, v are this rank's keyframes; the bank is everybody's (register_frame_shard)
+            out = shard.pivotal_attention(q, k, v, self.heads, self.scale, inject)
+        else:
+            out = ops.ext_attn(q, k, v, self.heads, self.scale, inject)
         return to_out(out if out.dtype == proj_dtype else out.to(proj_dtype))
 
     return forward
@@ -457,11 +486,22 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
                 self._tf_pivots = src.to(ops.compute_dtype(src)).contiguous()       # [K,S,D] 16-bit
                 self._tf_pivot_inv_norm = (norm_inv.view(3, n_frames, sequence_length)[0] if norm_inv is not None
                                            else ops.pivot_inv_norm(self._tf_pivots))   # [K,S] fp32
+                shard = _active_shard(self)
+                if shard is not None:
+                    if n_frames != shard.Kl:
+                        raise ValueError(f"pivotal pass with {n_frames} keyframes per branch on a rank that owns "
+                                         f"{shard.Kl} (register_frame_shard)")
+                    # the pivots' half of the neighbour halo does not depend on the attention: it travels under it
+                    halo = shard.halo_start(self._tf_pivots, self._tf_pivot_inv_norm.contiguous())
                 self.attn_output = self.attn1(
                     norm_hidden_states.view(batch_size, sequence_length, dim),
                     encoder_hidden_states=encoder_hidden_states if self.only_cross_attention else None,
                     **cross_attention_kwargs)
                 self.kf_attn_output = self.attn_output
+                if shard is not None:   # (pivots, inverse norms, attention output) with the neighbour's slot in front,
+                    # and the pending requests of the exchange: the first chunk pass waits for them
+                    self.__dict__["_tf_halo"] = shard.halo_finish(
+                        halo, self.kf_attn_output.reshape(batch_size, sequence_length, dim).contiguous(), wait=False)
                 if self.use_ada_layer_norm_zero:
                     self.attn_output = gate_msa.unsqueeze(1) * self.attn_output
                 attn_output = self.attn_output
@@ -473,14 +513,26 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
                     raise ValueError(f"{n_frames} frames per branch do not split into {n_chunks} chunks")
                 n = n_frames // n_chunks
                 kf = self.kf_attn_output
+                piv, inv = self._tf_pivots, self._tf_pivot_inv_norm
+                s0 = c0                 # slot of keyframe c0 in kf / piv / inv (one process: the keyframe index itself)
+                shard = _active_shard(self)
+                if shard is not None:   # this rank's caches: slot 0 = the left neighbour's last keyframe, then its own
+                    if not (shard.kf0 <= c0 and c0 + n_chunks <= shard.kf0 + shard.Kl):
+                        raise ValueError(f"chunks {c0}..{c0 + n_chunks - 1} are not owned by this rank "
+                                         f"({shard.kf0}..{shard.kf0 + shard.Kl - 1})")
+                    piv, inv, kf, reqs = self.__dict__["_tf_halo"]
+                    if reqs:
+                        shard.halo_wait(reqs)
+                        self.__dict__["_tf_halo"] = (piv, inv, kf, [])
+                    s0 = c0 - shard.kf0 + 1
                 K = kf.shape[0] // 3
                 if self.use_ada_layer_norm_zero:
                     # 362-366: the reference gates the SELECTED keyframe outputs before the gather:
                     # `attn_output = gate_msa.unsqueeze(1) * kf_attn_output.view(3,K,S,D)[:, batch_idxs]`.  Same
                     # torch expression here (same broadcasting, same promotion) on the keyframes this pass reads;
                     # the gated copy becomes the gather source, re-indexed from 0.
-                    lo = max(c0 - 1, 0)
-                    sel = kf.view(3, K, sequence_length, dim)[:, lo:c0 + n_chunks]
+                    lo = s0 - 1 if c0 > 0 else s0
+                    sel = kf.view(3, K, sequence_length, dim)[:, lo:s0 + n_chunks]
                     kf = (gate_msa.unsqueeze(1) * sel).reshape(-1, sequence_length, dim)
                     self.attn_output = kf.view(3, -1, sequence_length, dim)
                     kf_base, K = lo, kf.shape[0] // 3
@@ -496,7 +548,6 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
                 out_dtype = torch.promote_types(blend_dtype, hidden_states.dtype)
                 w = _blend_weights(n, kf.device) if two else None
                 resid = hidden_states.reshape(batch_size, sequence_length, dim)
-                piv, inv = self._tf_pivots, self._tf_pivot_inv_norm
                 if kf_base:      # gated copy holds keyframes kf_base.. only: search the same window of the pivots
                     piv, inv = piv[kf_base:kf_base + K], inv[kf_base:kf_base + K]
                 # the norm that consumes this pass's residual stream next (norm2 in front of the cross-attention, else
@@ -513,10 +564,10 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
                     if ndt is not None and ops.norm_fusable(kf, resid, out_dtype, 2 if two else 1, ndt):
                         fuse = (nxt[1].weight, nxt[1].bias, nxt[1].eps, ndt)
                 if n_chunks == 1:
-                    ids = [c0 - kf_base] if c0 == 0 else [c0 - kf_base, c0 - 1 - kf_base]
+                    ids = [s0 - kf_base] if c0 == 0 else [s0 - kf_base, s0 - 1 - kf_base]
                     res = ops.propagate(tgt, piv, inv, ids, kf, w, n, resid, out_dtype, norm=fuse)
                 else:
-                    res = ops.propagate_chunks(tgt, piv, inv, kf, w, n, n_chunks, c0 - kf_base, c0 == 0, resid,
+                    res = ops.propagate_chunks(tgt, piv, inv, kf, w, n, n_chunks, s0 - kf_base, c0 == 0, resid,
                                                out_dtype, norm=fuse)
                 if fuse is not None:
                     hidden_states, prenorm = res[0], (nxt[0], res[1])
