@@ -478,11 +478,15 @@ def test_fused_qkv_projection_matches_separate_projections(monkeypatch):
     g = torch.Generator().manual_seed(2)
     x = torch.randn(3 * K, S, 640, generator=g).cuda().bfloat16()
     enc = torch.randn(3 * K, 7, 32, generator=g).cuda().bfloat16()
-    qkv = hooks._fused_qkv(blk.attn1, x)
-    assert qkv is not None and qkv.shape == (3 * K, S, 1920) and qkv.dtype == torch.bfloat16
-    for i, lin in enumerate((blk.attn1.to_q, blk.attn1.to_k, blk.attn1.to_v)):
-        a, b = qkv[..., 640 * i:640 * (i + 1)].float(), lin(x).float()
-        assert float(((a - b).abs() - 2.0 ** -7 * b.abs()).max()) <= 1e-6
+    # while autograd is recording and the weights require grad the fused form steps aside (the cached concatenation is
+    # built without autograd): the three Linear calls stay
+    assert hooks._fused_qkv(blk.attn1, x) is None
+    with torch.no_grad():
+        qkv = hooks._fused_qkv(blk.attn1, x)
+        assert qkv is not None and qkv.shape == (3 * K, S, 1920) and qkv.dtype == torch.bfloat16
+        for i, lin in enumerate((blk.attn1.to_q, blk.attn1.to_k, blk.attn1.to_v)):
+            a, b = qkv[..., 640 * i:640 * (i + 1)].float(), lin(x).float()
+            assert float(((a - b).abs() - 2.0 ** -7 * b.abs()).max()) <= 1e-6
     outs = []
     for fuse in (True, False):
         monkeypatch.setattr(hooks, "FUSE_QKV", fuse)
@@ -493,8 +497,8 @@ def test_fused_qkv_projection_matches_separate_projections(monkeypatch):
     # the cache follows the weights
     with torch.no_grad():
         blk.attn1.to_k.weight.mul_(2.0)
-    assert torch.allclose(hooks._fused_qkv(blk.attn1, x)[..., 640:1280].float(), blk.attn1.to_k(x).float(),
-                          rtol=2.0 ** -6, atol=1e-3)
+        assert torch.allclose(hooks._fused_qkv(blk.attn1, x)[..., 640:1280].float(), blk.attn1.to_k(x).float(),
+                              rtol=2.0 ** -6, atol=1e-3)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
