@@ -2,7 +2,5 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03final; mkdir -p $O
 cd $R
-timeout 2400 python -m pytest tests/ -x -q -m gpu > $O/tests.txt 2>&1; echo "rc=$?" >> $O/tests.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "rc=$?" >> $O/smoke.txt
-timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "rc=$?" >> $O/bench.err
+timeout 3000 python -m pytest tests/ -q -m gpu > $O/tests.txt 2>&1; echo "rc=$?" >> $O/tests.txt
 ls $O
