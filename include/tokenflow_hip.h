@@ -382,6 +382,9 @@ int tf_sendrecv_pivot(tf_comm* comm, const void* const* send, const int64_t* sen
  * ------------------------------------------------------------------------ */
 #define TF_RANK_HEADS 0
 #define TF_RANK_BANK 1
+#define TF_RANK_NO_HALO 16   /* or-ed into `mode`: the attention alone -- kfo_ext is a plain [3, Kl, S, H*Dh] output, piv_ext /
+                                inv_ext are not read (NULL allowed), no neighbour exchange (hosts whose cached attention
+                                output is not this one: the hook path caches it after the to_out projection) */
 #define TF_RANK_SLOTS 64
 typedef struct tf_rank tf_rank;
 int tf_rank_create(tf_comm* comm, tf_comm* halo_comm, int K, tf_rank** rank_out);

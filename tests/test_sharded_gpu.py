@@ -337,6 +337,13 @@ def _native_worker(rank, world, port, K, h, inject, mode, split, ret):
                 ok = ok and torch.equal(pe[0], piv[f0 - 1]) and torch.equal(ie[0], inv[f0 - 1])
                 if not split:
                     ok = ok and torch.equal(ke.view(3, Kl + o, S, D)[:, 0], full.view(3, K, S, D)[:, f0 - 1])
+        # the attention alone (TF_RANK_NO_HALO: what the hook path calls from attn1), strided q/k/v slabs of one buffer
+        qkv = torch.cat([loc(q), loc(k), loc(v)], dim=-1)
+        qs, ks, vs = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        a_n = sh.pivotal_attention(qs, ks, vs, h, d ** -0.5, inject, mode=mode)
+        a_p = py.pivotal_attention(qs, ks, vs, h, d ** -0.5, inject, mode=mode)
+        torch.cuda.synchronize()
+        ok = ok and torch.equal(a_n, a_p) and (split or torch.equal(a_n, loc(full)))
         # native and Python forms: the same bits in every buffer they fill (the unset halo slot of rank 0 excluded)
         lo = 0 if rank > 0 else o
         (got_n, pe_n, ie_n, ke_n, first_n), (got_p, pe_p, ie_p, ke_p, first_p) = outs

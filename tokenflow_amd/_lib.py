@@ -11,7 +11,7 @@ TF_ATTN_INJECT, TF_ATTN_EXACT_SCALE, TF_ATTN_BANK_ONLY, TF_ATTN_SOURCE_ONLY, TF_
 TF_ATTN_OUT_F32 = 32
 TF_ATTN_FOLD_SCALE = 64
 ABI_VERSION = 4
-TF_RANK_HEADS, TF_RANK_BANK, TF_RANK_SLOTS = 0, 1, 64
+TF_RANK_HEADS, TF_RANK_BANK, TF_RANK_SLOTS, TF_RANK_NO_HALO = 0, 1, 64, 16
 TF_ERR_COMM = -6
 
 _c = ctypes

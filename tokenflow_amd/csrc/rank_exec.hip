@@ -170,7 +170,10 @@ extern "C" size_t tf_rank_pivotal_workspace_bytes(const tf_rank* rk, int S, int 
 extern "C" int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const void* v, const int64_t* st_in,
                                void* piv_ext, float* inv_ext, void* kfo_ext, int S, int H, int Dh, float scale,
                                int flags, int dtype, int mode, int slot, void* ws, size_t ws_bytes, void* stream) {
-    TF_ARG(rk && q && k && v && st_in && piv_ext && inv_ext && kfo_ext && ws, TF_ERR_NULL, "tf_rank_pivotal: null pointer");
+    const bool no_halo = (mode & TF_RANK_NO_HALO) != 0;   // attention only: kfo_ext is a plain [3, Kl, S, H*Dh] output
+    mode &= ~TF_RANK_NO_HALO;
+    TF_ARG(rk && q && k && v && st_in && kfo_ext && ws && (no_halo || (piv_ext && inv_ext)), TF_ERR_NULL,
+           "tf_rank_pivotal: null pointer");
     TF_ARG(dtype == TF_BF16 || dtype == TF_F16, TF_ERR_DTYPE, "tf_rank_pivotal: dtype %d (bf16/f16 only)", dtype);
     TF_ARG(mode == TF_RANK_HEADS || mode == TF_RANK_BANK, TF_ERR_SHAPE, "tf_rank_pivotal: mode %d", mode);
     TF_ARG(slot >= 0 && slot < TF_RANK_SLOTS, TF_ERR_SHAPE, "tf_rank_pivotal: slot %d outside [0, %d)", slot, TF_RANK_SLOTS);
@@ -178,7 +181,7 @@ extern "C" int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const 
            "tf_rank_pivotal: the part flags are the executor's own");
     TF_ARG(ws_bytes >= tf_rank_pivotal_workspace_bytes(rk, S, H, Dh, dtype), TF_ERR_WORKSPACE,
            "tf_rank_pivotal: workspace %zu < %zu bytes", ws_bytes, tf_rank_pivotal_workspace_bytes(rk, S, H, Dh, dtype));
-    const int W = rk->world, Kl = rk->Kl, K = rk->K, o = W > 1 ? 1 : 0;
+    const int W = rk->world, Kl = rk->Kl, K = rk->K, o = (W > 1 && !no_halo) ? 1 : 0;
     const int64_t D = (int64_t)H * Dh, SD = (int64_t)S * D;
     const int64_t q_bs = st_in[0], q_fs = st_in[1], k_bs = st_in[2], k_fs = st_in[3], v_bs = st_in[4], v_fs = st_in[5],
                   ld_q = st_in[6], ld = st_in[7];
@@ -193,7 +196,7 @@ extern "C" int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const 
     const int64_t o_bs = (int64_t)(Kl + o) * SD;   // branch stride of the halo-extended attention output
     E* out_loc = kfo + (int64_t)o * SD;            // its local slots
     const int inject = flags & TF_ATTN_INJECT;
-    rk->halo_set[slot] = false;
+    if (!no_halo) rk->halo_set[slot] = false;
 
     if (W == 1) {
         const int64_t strides[9] = {q_bs, q_fs, k_bs, k_fs, v_bs, v_fs, o_bs, SD, ld_q};
@@ -296,7 +299,7 @@ extern "C" int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const 
 
     // ---- neighbour halo: the last local keyframe's pivots, inverse norms and attention output -> slot 0 of rank r+1
     const int to = rk->rank + 1 < W ? rk->rank + 1 : -1, from = rk->rank > 0 ? rk->rank - 1 : -1;
-    if (to >= 0 || from >= 0) {
+    if (!no_halo && (to >= 0 || from >= 0)) {
         if (const int rc = order(rk, st, rk->hs, "tf_rank_pivotal")) return rc;
         const void* s16[4] = {piv + (int64_t)Kl * SD, kfo + (int64_t)Kl * SD, kfo + o_bs + (int64_t)Kl * SD,
                               kfo + 2 * o_bs + (int64_t)Kl * SD};

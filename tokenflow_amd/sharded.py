@@ -573,20 +573,39 @@ class NativeShard(FrameShard):
         except Exception:  # noqa: BLE001  (interpreter shutdown)
             pass
 
+    def pivotal_attention(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool,
+                          mode: Optional[str] = None, out4: Optional[torch.Tensor] = None):
+        """`FrameShard.pivotal_attention` as one library call (tf_rank_pivotal with TF_RANK_NO_HALO): what the hook path
+        calls from `attn1` (its cached attention output is the to_out-projected one, so the halo stays the block's)."""
+        if self.world == 1 or out4 is not None or not q_local.is_cuda or q_local.dtype not in (torch.bfloat16,
+                                                                                                torch.float16):
+            return super().pivotal_attention(q_local, k_local, v_local, heads, scale, inject, mode=mode, out4=out4)
+        B, S, D = q_local.shape
+        out = torch.empty(3, self.Kl, S, D, dtype=q_local.dtype, device=q_local.device)
+        self._native(q_local, k_local, v_local, heads, scale, inject, mode, None, None, out, no_halo=True)
+        return out.view(B, S, D)
+
     def pivotal_block(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool, ext,
                       mode: Optional[str] = None):
-        from . import _lib
-        lib = _lib.load()
         piv, inv, kfo = ext
         B, S, D = q_local.shape
         Kl = self.Kl
         o = 1 if self.world > 1 else 0
+        slot = self._native(q_local, k_local, v_local, heads, scale, inject, mode, piv, inv, kfo, no_halo=False)
+        reqs = [_SlotWait(self, slot, q_local.device)] if self.world > 1 else []
+        return piv, inv, kfo.view(3 * (Kl + o), S, D), reqs
+
+    def _native(self, q_local, k_local, v_local, heads, scale, inject, mode, piv, inv, kfo, no_halo):
+        from . import _lib
+        lib = _lib.load()
+        B, S, D = q_local.shape
+        Kl = self.Kl
         if mode is None:
             mode = self.auto_mode(heads, S)
         dt = ops._DT.get(q_local.dtype)
-        if dt is None or dt == _lib.TF_F32 or not (q_local.is_cuda and piv.is_contiguous() and inv.is_contiguous()
-                                                    and kfo.is_contiguous()):
-            raise TypeError("NativeShard.pivotal_block: 16-bit GPU tensors, contiguous halo-extended buffers")
+        if dt is None or dt == _lib.TF_F32 or not (q_local.is_cuda and kfo.is_contiguous()
+                                                    and (no_halo or (piv.is_contiguous() and inv.is_contiguous()))):
+            raise TypeError("NativeShard: 16-bit GPU tensors, contiguous (halo-extended) buffers")
 
         def frames(t):     # [3*Kl, S, D] (token stride free) -> [3, Kl, S, D] view
             if t.stride(2) != 1 or t.stride(0) != S * t.stride(1):
@@ -607,12 +626,13 @@ class NativeShard(FrameShard):
         if ops.FOLD_SCALE:
             flags |= _lib.TF_ATTN_FOLD_SCALE
         slot = self._slot
-        self._slot = (slot + 1) % _lib.TF_RANK_SLOTS
-        rc = lib.tf_rank_pivotal(self._rk, q3.data_ptr(), k3.data_ptr(), v3.data_ptr(), strides, piv.data_ptr(),
-                                 inv.data_ptr(), kfo.data_ptr(), S, heads, dh, float(scale), flags, dt,
-                                 _lib.TF_RANK_HEADS if mode == "heads" else _lib.TF_RANK_BANK, slot, ws.data_ptr(),
+        if not no_halo:
+            self._slot = (slot + 1) % _lib.TF_RANK_SLOTS
+        m = (_lib.TF_RANK_HEADS if mode == "heads" else _lib.TF_RANK_BANK) | (_lib.TF_RANK_NO_HALO if no_halo else 0)
+        rc = lib.tf_rank_pivotal(self._rk, q3.data_ptr(), k3.data_ptr(), v3.data_ptr(), strides,
+                                 None if piv is None else piv.data_ptr(), None if inv is None else inv.data_ptr(),
+                                 kfo.data_ptr(), S, heads, dh, float(scale), flags, dt, m, slot, ws.data_ptr(),
                                  ws.numel(), torch.cuda.current_stream(q_local.device).cuda_stream)
         if rc:
             _lib.check(rc, "tf_rank_pivotal")
-        reqs = [_SlotWait(self, slot, q_local.device)] if self.world > 1 else []
-        return piv, inv, kfo.view(3 * (Kl + o), S, D), reqs
+        return slot
