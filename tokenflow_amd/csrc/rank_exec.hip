@@ -247,12 +247,18 @@ extern "C" int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const 
         TF_HIP(hipStreamWaitEvent(st, arrived, 0), "tf_rank_pivotal");
         {
             const int64_t fs_r = ns * Shd;          // frame stride of recv [K][ns][S][hd]
+            // base such that branch b sits at base + b * Shd (the strided entry point's convention): a bank-only call
+            // never touches branch 0, so the base may lie one slab in front of the buffer -- formed as an integer
+            auto slab = [&](const E* buf, int64_t first_slab, int first_branch) {
+                return reinterpret_cast<const E*>(reinterpret_cast<uintptr_t>(buf) +
+                                                  (uintptr_t)((first_slab - first_branch) * Shd * (int64_t)sizeof(E)));
+            };
             const E *qb, *kb, *vb;
-            if (inject)
-                qb = recv, kb = recv + Shd, vb = recv + 2 * Shd - Shd;          // v slabs 2, 3 are branches 1, 2
-            else
-                qb = recv - Shd, kb = recv + 2 * Shd - Shd, vb = recv + 4 * Shd - Shd;   // slabs (0,1), (2,3), (4,5)
-            E* ob = send2 - Shd;                                                 // send2 [K][uncond|cond][S][hd]
+            if (inject)    // slabs [q0, k0, v1, v2]
+                qb = slab(recv, 0, 0), kb = slab(recv, 1, 0), vb = slab(recv, 2, 1);
+            else           // slabs [q1, q2, k1, k2, v1, v2]
+                qb = slab(recv, 0, 1), kb = slab(recv, 2, 1), vb = slab(recv, 4, 1);
+            E* ob = const_cast<E*>(slab(send2, 0, 1));                           // send2 [K][uncond|cond][S][hd]
             const int64_t strides[9] = {Shd, fs_r, Shd, fs_r, Shd, fs_r, Shd, 2 * Shd, hd};
             if (const int rc = tf_ext_attn_fwd_strided(qb, kb, vb, ob, K, K, 0, S, Hl, Dh, hd, strides, scale,
                                                        flags | TF_ATTN_BANK_ONLY, dtype, wsb + L.ws_bank, L.ws_bank_bytes,
