@@ -183,7 +183,9 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const typename T::elem* __
 // MINW = min waves per SIMD for the register allocator
 // FQ   = fold the softmax scale into Q (see FOLD below; opt-in, TF_ATTN_FOLD_SCALE); false = the default, fp32
 //        scaling of the scores as the reference does (tokenflow_utils.py:173-175 `* self.scale` on the bmm output)
-template <typename T, int DH, int QT, int NW, int MODE, int MINW, int KT, bool FQ>
+// SB   = single LDS buffer (two barriers per tile) instead of two: half the LDS per workgroup.  For head dim 160, where
+//        the double-buffered tiles (89 KB) allow ONE workgroup per CU and a wave waits alone for every 1 KB fragment
+template <typename T, int DH, int QT, int NW, int MODE, int MINW, int KT, bool FQ, bool SB = false>
 __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     typedef AttnCfg<DH, KT> C;
     typedef typename T::elem E;
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     constexpr int NT = 64 * NW;
     constexpr int NB = MODE == MODE_DUAL ? 2 : 1;   // V banks handled by this workgroup
     constexpr int NPK = C::npk(NT), NPV = C::npv(NT);
+    constexpr int NBUFS = SB ? 1 : 2;
     // PACK (dual-V at Dh = 40): the two banks' V^T rows share ONE LDS image of 3 M-tiles -- rows 0-39 uncond,
     // 40-79 cond, row 80 = 1.0 (the common denominator row), 81-95 zero -- instead of two images of 2 M-tiles
     // with 24 idle rows each: 12 instead of 16 P.V MFMAs per 64-key tile (18 instead of 22 with QK^T).
@@ -294,20 +297,20 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     // ---- LDS pads, written once and never staged over: K columns DH..DKP-1 = 0,
     //      V^T rows DH..VROWS-1 = 0 except row DH = 1 (denominator row) when ONES.
     if constexpr (C::DKP > DH) {
-        for (int id = tid; id < 2 * KT * (C::DKP - DH); id += NT) {
+        for (int id = tid; id < NBUFS * KT * (C::DKP - DH); id += NT) {
             const int bufi = id / (KT * (C::DKP - DH));
             const int r = (id / (C::DKP - DH)) % KT, cidx = id % (C::DKP - DH);
             sK(bufi)[r * C::KROW + DH + cidx] = (E)((FOLD && cidx == 0) ? 1.f : 0.f);
         }
     }
     if constexpr (PACK) {
-        for (int id = tid; id < 2 * (VIMG_ROWS - NB * DH) * KT; id += NT) {
+        for (int id = tid; id < NBUFS * (VIMG_ROWS - NB * DH) * KT; id += NT) {
             const int bufi = id / ((VIMG_ROWS - NB * DH) * KT);
             const int r = (id / KT) % (VIMG_ROWS - NB * DH), cidx = id % KT;
             sV(bufi, 0)[(NB * DH + r) * C::VROW + cidx] = (E)(r == 0 ? 1.f : 0.f);
         }
     } else if constexpr (C::VROWS > DH) {
-        for (int id = tid; id < 2 * NB * (C::VROWS - DH) * KT; id += NT) {
+        for (int id = tid; id < NBUFS * NB * (C::VROWS - DH) * KT; id += NT) {
             const int bv = id / ((C::VROWS - DH) * KT);
             const int r = (id / KT) % (C::VROWS - DH), cidx = id % KT;
             sV(bv / NB, bv % NB)[(DH + r) * C::VROW + cidx] = (E)((ONES && r == 0) ? 1.f : 0.f);
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
 
     int tt_cur = 0;   // tile index within the frame of the tile being computed
     for (int tile = 0; tile < ntiles; ++tile) {
-        const int buf = tile & 1;
+        const int buf = SB ? 0 : tile & 1;
         const bool has_next = tile + 1 < ntiles;
         if (has_next) stage_load();
 
@@ -595,7 +598,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
 
         }
 
-        if (has_next) stage_write(buf ^ 1);
+        if constexpr (SB) {
+            if (has_next) {
+                __syncthreads();   // every wave is done reading the tile before it is overwritten
+                stage_write(0);
+            }
+        } else if (has_next) {
+            stage_write(buf ^ 1);
+        }
         tt_cur = tt_cur == tpf - 1 ? 0 : tt_cur + 1;
         __syncthreads();
     }
@@ -736,7 +746,10 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
 static int split_plan(int K, int Kq, int S, int H, int Dh, bool inject, int part, bool allow) {
     if (!allow || part == TF_ATTN_SOURCE_ONLY) return 1;
     const bool dual = inject && S >= 256 && Dh != 160;
-    const int occ = Dh == 40 ? (dual ? 3 : 4) : Dh == 160 ? 1 : (dual ? 2 : 3);   // waves per SIMD the kernels reach
+#ifndef TF_TUNE_OCC160
+#define TF_TUNE_OCC160 1   // splitting towards 2 waves per SIMD (the single-buffered tiles would allow two workgroups per
+#endif                     // CU) measured slower: 88 vs 85 us at cfg2 level 2, 41 vs 33 us on a rank of 8 (merge included)
+    const int occ = Dh == 40 ? (dual ? 3 : 4) : Dh == 160 ? TF_TUNE_OCC160 : (dual ? 2 : 3);   // waves per SIMD the kernels reach
     const int64_t wgs = (int64_t)(dual ? 1 : 2) * Kq * ((S + 127) / 128) * H;   // 4-wave workgroups
     const int tpf = (S + 63) / 64;
     if (K * tpf < 16) return 1;   // a bank of a few tiles: the merge launch costs more than it buys (8x8 level)
@@ -1594,12 +1607,12 @@ int launch_pp(AttnParams p, hipStream_t st) {
     return 0;
 }
 
-template <typename T, int DH, int QT, int NW, int MODE, int MINW, bool FQ = true, int KT = 64>
+template <typename T, int DH, int QT, int NW, int MODE, int MINW, bool FQ = true, int KT = 64, bool SB = false>
 int launch_one(AttnParams p, hipStream_t st) {
     typedef AttnCfg<DH, KT> C;
-    constexpr size_t lds = (MODE == MODE_DUAL && DH == 40) ? 2 * (size_t)(C::K_ELEMS + 96 * C::VROW) * 2   // PACK
-                                                            : C::lds_bytes(MODE == MODE_DUAL ? 2 : 1);
-    auto kern = ext_attn_kernel<T, DH, QT, NW, MODE, MINW, KT, FQ>;
+    constexpr size_t lds = ((MODE == MODE_DUAL && DH == 40) ? 2 * (size_t)(C::K_ELEMS + 96 * C::VROW) * 2   // PACK
+                                                             : C::lds_bytes(MODE == MODE_DUAL ? 2 : 1)) / (SB ? 2 : 1);
+    auto kern = ext_attn_kernel<T, DH, QT, NW, MODE, MINW, KT, FQ, SB>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     p.nQT = (p.S + 32 * QT * NW - 1) / (32 * QT * NW);
@@ -1718,8 +1731,15 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
         // was measured here too (8 waves sharing the 89 KB of tiles, 237 VGPRs): 97 vs 92 us at cfg2 level 2 -- at
         // this head dim every MFMA needs its own 1 KB fragment from LDS, whose read rate (128 B/clk per CU) equals
         // the matrix pipes' demand, and the level has one wave per SIMD whatever the kernel.
+#ifndef TF_TUNE_DB160
+        // single LDS buffer: 44.5 instead of 89 KB per workgroup.  85 vs 95 us at cfg2 level 2 (profiles/r03_attn_sb160.txt):
+        // at one wave per SIMD the second buffer bought no overlap, and two workgroups now fit a CU where the grid has them
+        if (src_only) return launch_one<T, DH, 1, 4, MODE_SOURCE, 1, true, 64, true>(p, st);
+        const int rc = launch_one<T, DH, 1, 4, MODE_ALL, 1, true, 64, true>(p, st);
+#else
         if (src_only) return launch_one<T, DH, 1, 4, MODE_SOURCE, 1>(p, st);
         const int rc = launch_one<T, DH, 1, 4, MODE_ALL, 1>(p, st);
+#endif
         return rc ? rc : merge();
     }
 }
