@@ -307,15 +307,13 @@ extern "C" int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const 
     const int to = rk->rank + 1 < W ? rk->rank + 1 : -1, from = rk->rank > 0 ? rk->rank - 1 : -1;
     if (!no_halo && (to >= 0 || from >= 0)) {
         if (const int rc = order(rk, st, rk->hs, "tf_rank_pivotal")) return rc;
-        const void* s16[4] = {piv + (int64_t)Kl * SD, kfo + (int64_t)Kl * SD, kfo + o_bs + (int64_t)Kl * SD,
-                              kfo + 2 * o_bs + (int64_t)Kl * SD};
-        void* r16[4] = {piv, kfo, kfo + o_bs, kfo + 2 * o_bs};
-        const int64_t n16[4] = {SD, SD, SD, SD};
-        if (const int rc = tf_sendrecv_pivot(rk->halo_comm, s16, n16, 4, to, r16, n16, 4, from, dtype, rk->hs)) return rc;
-        const void* s32[1] = {inv_ext + (int64_t)Kl * S};
-        void* r32[1] = {inv_ext};
-        const int64_t n32[1] = {S};
-        if (const int rc = tf_sendrecv_pivot(rk->halo_comm, s32, n32, 1, to, r32, n32, 1, from, TF_F32, rk->hs)) return rc;
+        // ONE grouped exchange for the five messages (the entry point moves bytes: the 16-bit rows are counted as
+        // SD/2 four-byte elements next to the fp32 inverse norms; S*D is even, D being a multiple of 8)
+        const void* snd[5] = {piv + (int64_t)Kl * SD, kfo + (int64_t)Kl * SD, kfo + o_bs + (int64_t)Kl * SD,
+                              kfo + 2 * o_bs + (int64_t)Kl * SD, inv_ext + (int64_t)Kl * S};
+        void* rcv[5] = {piv, kfo, kfo + o_bs, kfo + 2 * o_bs, inv_ext};
+        const int64_t n32[5] = {SD / 2, SD / 2, SD / 2, SD / 2, S};
+        if (const int rc = tf_sendrecv_pivot(rk->halo_comm, snd, n32, 5, to, rcv, n32, 5, from, TF_F32, rk->hs)) return rc;
         TF_HIP(hipEventRecord(rk->halo_done[slot], rk->hs), "tf_rank_pivotal");
         rk->halo_set[slot] = true;
     }
