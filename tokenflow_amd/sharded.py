@@ -32,7 +32,16 @@ side stream ordered against the compute stream with events):
 
  2. propagation passes -- chunk c needs keyframes c and c-1 (331-333): the first local chunk's
     left neighbour lives on rank r-1, so each rank sends its LAST keyframe's pivot features,
-    inverse norms and attention output to rank r+1 (one point-to-point message per block).
+    inverse norms and attention output to rank r+1: one grouped point-to-point exchange per block
+    (`pivotal_block`, the in-place form: the block's propagation state lives in halo-extended buffers
+    from `ext_alloc` that the producers write directly) or two (`halo_start` before the attention,
+    `halo_finish` after it), on a communicator / process group and side stream of its own when the
+    host provides one (`halo_comm` / `halo_group`).
+
+Three hosts run this sequence with identical results: `FrameShard` over torch.distributed, `FrameShard`
+over the library's exchange entry points (`comm=`), and `NativeShard` (bottom of this file), whose
+pivotal pass of a block is ONE library call (tf_rank_pivotal, csrc/rank_exec.hip).  The hook API
+reaches them through `tokenflow_amd.hooks.register_frame_shard`.
 
 Work is partitioned, not re-associated: every output element is produced by exactly the same
 kernel arithmetic as on one GPU (the attention of one (query, head) visits the K frames in the
