@@ -54,7 +54,7 @@ rounding, because the merge re-associates fp32 sums.
 """
 import ctypes
 import os
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 import torch.distributed as dist
