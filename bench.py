@@ -610,15 +610,19 @@ def main():
             traffic_src = tj.get("source")
         except Exception:
             traffic = None
+    kname = {40: "ext_attn_il_kernel<BF16, 40, 8, MODE_ALL, 4> (half-tile interleaved)",
+             64: "ext_attn_pp_kernel<BF16, 64, MODE_ALL, 2> (ping-pong)",
+             80: "ext_attn_il_kernel<BF16, 80, 8, MODE_ALL, 2> (half-tile interleaved)"}.get(
+                 dh0, "ext_attn_kernel<BF16, %d, ..., MODE_ALL>" % dh0)
     plain = roof(False, blk0.attn_flops, {
-        "kernel": "ext_attn_kernel<bf16, Dh=%d, MODE_ALL> level 0, no q/k injection (+ V^T pre-pass inside the event "
-                  "bracket)" % dh0,
+        "kernel": kname + ", level 0, no q/k injection (+ vt_pack_kernel pre-pass inside the event bracket; N = 1 name: "
+                  "rocprofv3 prints the template arguments as <BF16; %d; ...; 0; ...>)" % dh0,
         "traffic": traffic,
         "traffic_source": traffic_src or "profiles/traffic.json (rocprofv3 --pmc passes of tools/attn_microbench.py; "
                                          "not measured in this run)"})
     dual = roof(True, blk0.attn_flops, {
-        "kernel": "dual-V kernel (uncond + cond share QK^T and the softmax) + source launch + V^T pre-pass, level 0, "
-                  "q/k injection on",
+        "kernel": ("ext_attn_il_kernel<BF16, 40, 4, MODE_DUAL, 3>" if dh0 == 40 else "the dual-V kernel")
+                  + " (uncond + cond share QK^T and the softmax) + source launch + V^T pre-pass, level 0, q/k injection on",
         "executed_gflop_per_launch": round(blk0.attn_flops_inject / 1e9, 1),
         "note": "achieved/frac use the ALGORITHMIC flops of the reference formulation; the launch executes fewer"})
     out = {
