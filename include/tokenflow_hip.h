@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TF_ABI_VERSION 4
+#define TF_ABI_VERSION 5
 
 /* element types */
 #define TF_BF16 0
@@ -45,6 +45,14 @@ extern "C" {
 #define TF_ATTN_NO_SPLIT 16    /* never split a bank problem over workgroups (one pass, bit-stable across grid sizes) */
 #define TF_ATTN_FOLD_SCALE 64  /* Dh = 40 only: fold scale*log2e into q, rounded to the input dtype (faster, less exact) */
 #define TF_ATTN_OUT_F32 32     /* `out` is float: the normalised fp32 accumulator, without the rounding to the 16-bit I/O type */
+#define TF_ATTN_NO_FUSED 128   /* never take the fused small-problem kernel (below): the streaming kernels at every size */
+#define TF_ATTN_FUSED (1 << 17) /* take the fused small-problem kernel at any size it is built for */
+/* tuning hints of the fused small-problem kernel (0 = automatic; A/B measurements, tools/attn_microbench.py) */
+#define TF_ATTN_HINT_QW(code) (((code) & 7) << 8)    /* code 1, 2, 3 = 1, 2, 4 query waves per workgroup */
+#define TF_ATTN_HINT_KW(code) (((code) & 7) << 11)   /* code 1, 2, 3 = 1, 2, 4 key groups per workgroup */
+#define TF_ATTN_HINT_VT_WRITE (1 << 14)              /* development builds only: V transposed by LDS writes */
+#define TF_ATTN_PRECISE_P (1 << 15)                  /* fused kernel, bf16: carry P as hi + lo whatever the size */
+#define TF_ATTN_NO_PRECISE_P (1 << 16)               /* fused kernel: P in one 16-bit value whatever the size */
 
 /* argument errors */
 #define TF_ERR_NULL (-1)
@@ -97,6 +105,14 @@ const char* tf_last_error(void);
  *   inject & TF_ATTN_OUT_F32: `out` is float [3, Kq, S, H*Dh]; the softmax-normalised fp32 accumulator is stored
  *   as is.  Removes the output rounding (2^-9 relative for bf16) from the result: the mode in which the
  *   "< 1e-3 per token" target of BASELINE.json holds for outputs of any magnitude.
+ *
+ *   Small problems -- S <= 256 always; S <= 1024 on small grids (a sharded rank, BASELINE config 1) unless
+ *   TF_ATTN_NO_SPLIT -- run in ONE fused launch (csrc/ext_attn_fused.hip): V is transposed inside the kernel
+ *   (ds_read_b64_tr_b16, no pre-pass), the key sequence is split over the wave groups of a workgroup and merged
+ *   through LDS (no partials, no merge launch), and for bf16 at S <= 256 P is carried as hi + lo bf16 so that the
+ *   rounding of P (2^-9; the reference's fp16 autocast path rounds to 2^-11 at this point) drops out of the result.
+ *   Which calls take it is a function of the SHAPE alone under TF_ATTN_NO_SPLIT, so one-pass results stay
+ *   bit-identical between a sharded rank and the single GPU; TF_ATTN_NO_FUSED keeps the streaming kernels.
  *
  *   ws: scratch for the transposed V bank (+ key norms, + split-form partials); size from
  *   tf_ext_attn_workspace_bytes.

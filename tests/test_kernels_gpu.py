@@ -85,7 +85,10 @@ def assert_attn_close(got, refs, what="", dtype=torch.bfloat16, folded=None):
 # --------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("name", list(gc.ATTN_CASES))
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_ext_attn_vs_oracle_and_golden(name, dtype, golden_attn):
+@pytest.mark.parametrize("fused", [None, False])
+def test_ext_attn_vs_oracle_and_golden(name, dtype, fused, golden_attn):
+    """fused=None: the library's own choice (the small golden cases run in the fused kernel, csrc/ext_attn_fused.hip);
+    fused=False: the streaming kernels on the same inputs (TF_ATTN_NO_FUSED)."""
     ops = _ops()
     K, S, h, d, sched, t = gc.ATTN_CASES[name]
     q, k, v = gc.attn_inputs(name)                       # fp32 holding bf16-representable values
@@ -94,7 +97,7 @@ def test_ext_attn_vs_oracle_and_golden(name, dtype, golden_attn):
         q, k, v = (x.to(torch.float16).float() for x in (q, k, v))
     refs = attn_ref(q, k, v, h, d ** -0.5, inject)
     dq, dk, dv = (x.to(dtype).cuda() for x in (q, k, v))
-    out = ops.ext_attn(dq, dk, dv, h, d ** -0.5, inject)
+    out = ops.ext_attn(dq, dk, dv, h, d ** -0.5, inject, fused=fused)
     torch.cuda.synchronize()
     assert out.dtype == dtype and out.shape == refs[0].shape
     assert_attn_close(out, refs, f"{name}/{dtype}", dtype)
@@ -105,7 +108,7 @@ def test_ext_attn_vs_oracle_and_golden(name, dtype, golden_attn):
         st = g["out_pnp"]["stride"]
         f, r = out.float().cpu().flatten()[::st], g["out_pnp"]["sample"]
         assert float(((f - r).abs() - attn_bound(r, refs[1].flatten()[::st])).max()) <= 0
-        out_sde = ops.ext_attn(dq, dk, dv, h, d ** -0.5, False)
+        out_sde = ops.ext_attn(dq, dk, dv, h, d ** -0.5, False, fused=fused)
         st = g["out_sdedit"]["stride"]
         f, r = out_sde.float().cpu().flatten()[::st], g["out_sdedit"]["sample"]
         r_sde = attn_ref(q, k, v, h, d ** -0.5, False, need_sigma=False)
@@ -126,19 +129,20 @@ def test_ext_attn_vs_oracle_and_golden(name, dtype, golden_attn):
                                      (2, 45, 2, 160), (3, 181, 2, 80), (2, 723, 1, 40), (2, 515, 1, 64), (1, 1, 1, 40)])
 @pytest.mark.parametrize("inject", [False, True])
 @pytest.mark.parametrize("no_split", [False, True])
-def test_ext_attn_shapes(K, S, h, d, inject, no_split, monkeypatch):
-    """Ragged S (not a multiple of 64 / 128), single keyframe, many heads, K > 12.  These grids are small, so by
-    default the bank problems run in the split form (runs of bank frames + merge); no_split forces the one-pass
-    form on the same inputs."""
+@pytest.mark.parametrize("fused", [None, False])
+def test_ext_attn_shapes(K, S, h, d, inject, no_split, fused, monkeypatch):
+    """Ragged S (not a multiple of 64 / 128), single keyframe, many heads, K > 12.  These grids are small: by default
+    they run in the fused small-problem kernel; fused=False keeps the streaming kernels, where the bank problems run in
+    the split form (runs of bank frames + merge) unless no_split forces the one-pass form on the same inputs."""
     ops = _ops()
     monkeypatch.setattr(ops, "NO_SPLIT", no_split)
     g = torch.Generator().manual_seed(K * 1000 + S + d)
     D = h * d
     q, k, v = (orc.bf16_round(torch.randn(3 * K, S, D, generator=g)) for _ in range(3))
     refs = attn_ref(q, k, v, h, d ** -0.5, inject)
-    out = ops.ext_attn(q.bfloat16().cuda(), k.bfloat16().cuda(), v.bfloat16().cuda(), h, d ** -0.5, inject)
-    assert_attn_close(out, refs, f"K{K} S{S} h{h} d{d} inj{inject} no_split{no_split}")
-    if d == 40:
+    out = ops.ext_attn(q.bfloat16().cuda(), k.bfloat16().cuda(), v.bfloat16().cuda(), h, d ** -0.5, inject, fused=fused)
+    assert_attn_close(out, refs, f"K{K} S{S} h{h} d{d} inj{inject} no_split{no_split} fused{fused}")
+    if d == 40 and fused is False:
         out = ops.ext_attn(q.bfloat16().cuda(), k.bfloat16().cuda(), v.bfloat16().cuda(), h, d ** -0.5, inject,
                            fold_scale=True)
         assert_attn_close(out, refs, f"fold K{K} S{S} h{h} d{d} inj{inject} no_split{no_split}", folded=True)
@@ -149,8 +153,9 @@ def test_ext_attn_shapes(K, S, h, d, inject, no_split, monkeypatch):
 @pytest.mark.parametrize("inject", [False, True])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_ext_attn_split_form(K, S, h, d, inject, dtype, monkeypatch):
-    """Shapes of a head-sharded rank (one head group, all keyframes): the bank is split into runs of frames over
-    extra workgroups and merged (attn_merge_kernel).  Against the oracle with the usual bound, and against the
+    """Shapes of a head-sharded rank (one head group, all keyframes) in the STREAMING kernels (fused=False; such
+    shapes run in the fused kernel by default, tests/test_fused_attn_gpu.py): the bank is split into runs of frames
+    over extra workgroups and merged (attn_merge_kernel).  Against the oracle with the usual bound, and against the
     one-pass form of the same call within the output rounding."""
     ops = _ops()
     g = torch.Generator().manual_seed(K * 77 + S + d)
@@ -160,10 +165,10 @@ def test_ext_attn_split_form(K, S, h, d, inject, dtype, monkeypatch):
     refs = attn_ref(q, k, v, h, d ** -0.5, inject)
     dq, dk, dv = (t.to(dtype).cuda() for t in (q, k, v))
     monkeypatch.setattr(ops, "NO_SPLIT", False)
-    out = ops.ext_attn(dq, dk, dv, h, d ** -0.5, inject)
+    out = ops.ext_attn(dq, dk, dv, h, d ** -0.5, inject, fused=False)
     assert_attn_close(out, refs, f"split K{K} S{S} h{h} d{d} inj{inject}", dtype=dtype)
     monkeypatch.setattr(ops, "NO_SPLIT", True)
-    one = ops.ext_attn(dq, dk, dv, h, d ** -0.5, inject)
+    one = ops.ext_attn(dq, dk, dv, h, d ** -0.5, inject, fused=False)
     assert_attn_close(one, refs, f"one-pass K{K} S{S} h{h} d{d} inj{inject}", dtype=dtype)
     diff = (out.float() - one.float()).abs().cpu()     # both within the bound of the oracle; typically 0 or 1 ulp apart
     ref, ref_abs, sigma = refs
@@ -199,8 +204,9 @@ def test_ext_attn_softmax_spike(d):
             k[b, (s * 5 + 150) % S] = q[b, s] * 3.0     # spike lands in the last 64-key tile for many queries
     q, k, v = (orc.bf16_round(x) for x in (q, k, v))
     refs = attn_ref(q, k, v, h, d ** -0.5, False)
-    out = ops.ext_attn(q.bfloat16().cuda(), k.bfloat16().cuda(), v.bfloat16().cuda(), h, d ** -0.5, False)
-    assert_attn_close(out, refs, f"spike d={d}")
+    for fused in (None, False):     # the fused small-problem kernel (default at this size) and the streaming kernels
+        out = ops.ext_attn(q.bfloat16().cuda(), k.bfloat16().cuda(), v.bfloat16().cuda(), h, d ** -0.5, False, fused=fused)
+        assert_attn_close(out, refs, f"spike d={d} fused={fused}")
     if d == 40:
         out_f = ops.ext_attn(q.bfloat16().cuda(), k.bfloat16().cuda(), v.bfloat16().cuda(), h, d ** -0.5, False,
                              fold_scale=True)
@@ -230,7 +236,7 @@ def test_ext_attn_folded_shift_paths(d, dtype, gain):
         refs = attn_ref(q, k, v, h, d ** -0.5, inject)
         for fold in ((False, True) if d == 40 else (False,)):
             out = ops.ext_attn(q.to(dtype).cuda(), k.to(dtype).cuda(), v.to(dtype).cuda(), h, d ** -0.5, inject,
-                               fold_scale=fold)
+                               fold_scale=fold, fused=False)     # the score bound is a streaming-kernel feature
             assert torch.isfinite(out.float()).all()
             assert_attn_close(out, refs, f"shift paths d={d} {dtype} gain={gain} inject={inject} fold={fold}",
                               dtype=dtype, folded=fold)
@@ -238,14 +244,15 @@ def test_ext_attn_folded_shift_paths(d, dtype, gain):
 
 @pytest.mark.parametrize("K,S,h,d", [(3, 320, 2, 40), (2, 136, 2, 40), (2, 520, 2, 64), (2, 264, 1, 80), (2, 72, 1, 160)])
 @pytest.mark.parametrize("inject", [False, True])
-def test_ext_attn_bank_and_source_parts(K, S, h, d, inject):
+@pytest.mark.parametrize("fused", [None, False])
+def test_ext_attn_bank_and_source_parts(K, S, h, d, inject, fused):
     """TF_ATTN_BANK_ONLY + TF_ATTN_SOURCE_ONLY together reproduce the full call bit for bit, write nothing
     outside their branches and never read the slabs they do not need (poisoned with NaN here)."""
     ops = _ops()
     D = h * d
     g = torch.Generator(device="cuda").manual_seed(23)
     q, k, v = (torch.randn(3 * K, S, D, generator=g, device="cuda").bfloat16() for _ in range(3))
-    full = ops.ext_attn(q, k, v, h, d ** -0.5, inject)
+    full = ops.ext_attn(q, k, v, h, d ** -0.5, inject, fused=fused)
     nan = float("nan")
 
     def poisoned(t, branches):
@@ -255,12 +262,12 @@ def test_ext_attn_bank_and_source_parts(K, S, h, d, inject):
     qk_unread = [1, 2] if inject else [0]
     out = torch.full_like(full, 7.0)
     ops.ext_attn(poisoned(q, qk_unread), poisoned(k, qk_unread), poisoned(v, [0]), h, d ** -0.5, inject, out=out,
-                 part="bank")
+                 part="bank", fused=fused)
     assert torch.equal(out.view(3, -1)[1:], full.view(3, -1)[1:])
     assert bool((out.view(3, -1)[0] == 7.0).all())
     out = torch.full_like(full, 7.0)
     ops.ext_attn(poisoned(q, [1, 2]), poisoned(k, [1, 2]), poisoned(v, [1, 2]), h, d ** -0.5, inject, out=out,
-                 part="source")
+                 part="source", fused=fused)
     assert torch.equal(out.view(3, -1)[0], full.view(3, -1)[0])
     assert bool((out.view(3, -1)[1:] == 7.0).all())
 

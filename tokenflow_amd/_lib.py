@@ -10,7 +10,18 @@ TF_BF16, TF_F16, TF_F32 = 0, 1, 2
 TF_ATTN_INJECT, TF_ATTN_EXACT_SCALE, TF_ATTN_BANK_ONLY, TF_ATTN_SOURCE_ONLY, TF_ATTN_NO_SPLIT = 1, 2, 4, 8, 16
 TF_ATTN_OUT_F32 = 32
 TF_ATTN_FOLD_SCALE = 64
-ABI_VERSION = 4
+TF_ATTN_NO_FUSED, TF_ATTN_FUSED = 128, 1 << 17
+TF_ATTN_HINT_VT_WRITE, TF_ATTN_PRECISE_P, TF_ATTN_NO_PRECISE_P = 1 << 14, 1 << 15, 1 << 16
+
+
+def attn_hint(qw: int = 0, kw: int = 0) -> int:
+    """TF_ATTN_HINT_QW / _KW bits of the fused small-problem kernel: qw in {0 (auto), 1, 2, 4} query waves per
+    workgroup, kw in {0 (auto), 1, 2, 4} key groups."""
+    code = {0: 0, 1: 1, 2: 2, 4: 3}
+    return (code[qw] << 8) | (code[kw] << 11)
+
+
+ABI_VERSION = 5
 TF_RANK_HEADS, TF_RANK_BANK, TF_RANK_SLOTS, TF_RANK_NO_HALO = 0, 1, 64, 16
 TF_ERR_COMM = -6
 

@@ -35,6 +35,7 @@
 //                                                in program order with the MFMAs of the other
 #include <type_traits>
 
+#include "attn_fused.h"
 #include "tf_common.h"
 
 namespace {
@@ -1795,6 +1796,22 @@ extern "C" int tf_ext_attn_fwd_strided(const void* q, const void* k, const void*
            TF_ERR_ALIGN, "tf_ext_attn_fwd: tensors not 16-byte aligned");
     TF_ARG(ws_bytes >= tf_ext_attn_workspace_bytes(K, S, H, Dh, dtype), TF_ERR_WORKSPACE,
            "tf_ext_attn_fwd: workspace %zu < %zu bytes", ws_bytes, tf_ext_attn_workspace_bytes(K, S, H, Dh, dtype));
+    const int part_bits = inject & (TF_ATTN_BANK_ONLY | TF_ATTN_SOURCE_ONLY);
+    TF_ARG(part_bits != (TF_ATTN_BANK_ONLY | TF_ATTN_SOURCE_ONLY), TF_ERR_SHAPE,
+           "tf_ext_attn_fwd: TF_ATTN_BANK_ONLY and TF_ATTN_SOURCE_ONLY exclude each other");
+    {   // small problems: one fused launch, no pre-pass, no merge (csrc/ext_attn_fused.hip)
+        TfAttnSet a{};
+        a.q = q, a.k = k, a.v = v, a.out = out;
+        a.q_bs = strides[0], a.q_fs = strides[1], a.ld_q = ld_q;
+        a.k_bs = strides[2], a.k_fs = strides[3], a.v_bs = strides[4], a.v_fs = strides[5], a.ld = ld;
+        a.o_bs = strides[6], a.o_fs = strides[7];
+        a.H = H, a.Kq = Kq, a.q_frame0 = q_frame0, a.Kb = K;
+        a.b0 = part_bits == TF_ATTN_BANK_ONLY ? 1 : 0;
+        a.nb = part_bits == TF_ATTN_BANK_ONLY ? 2 : part_bits == TF_ATTN_SOURCE_ONLY ? 1 : 3;
+        const TfFusedPlan plan = tf_attn_fused_plan(&a, 1, S, Dh, dtype, inject);
+        if (plan.use)
+            return tf_attn_fused_launch(&a, 1, S, Dh, scale, inject, dtype, plan, reinterpret_cast<hipStream_t>(stream));
+    }
     AttnParams p{};
     p.q = q;
     p.k = k;
@@ -1817,8 +1834,6 @@ extern "C" int tf_ext_attn_fwd_strided(const void* q, const void* k, const void*
     p.partials = reinterpret_cast<float*>(
         reinterpret_cast<unsigned char*>(const_cast<float*>(p.knorm2)) +
         (((size_t)3 * H * K * (((S + 127) / 128) * 128 / 64) * sizeof(float) + 255) & ~(size_t)255));
-    TF_ARG(p.part != (TF_ATTN_BANK_ONLY | TF_ATTN_SOURCE_ONLY), TF_ERR_SHAPE,
-           "tf_ext_attn_fwd: TF_ATTN_BANK_ONLY and TF_ATTN_SOURCE_ONLY exclude each other");
     p.ld = ld;
     p.ld_q = ld_q;
     p.q_bs = strides[0];

@@ -1,0 +1,502 @@
+// Fused small-problem form of the extended attention (tokenflow_utils.py:124-197 / 234-279 of omerbt/TokenFlow) for
+// gfx950: the coarse UNet levels (S <= 256), BASELINE config 1, and a frame-sharded rank's share of the middle levels.
+//
+// The streaming kernels of ext_attn.hip spend a V^T pre-pass, (on small grids) a split + merge launch pair and -- on a
+// sharded rank -- a separate source-branch launch around the attention itself.  At these sizes each of those launches
+// costs as much as the attention (4-30 us each).  This kernel needs none of them:
+//   * ONE launch over every (tensor set, branch, frame, head, 32*QW-query tile) problem; a sharded rank passes two
+//     tensor sets -- the bank branches on the buffer its all-to-all delivered and the source branch of its own frames;
+//   * V is staged ROW-major, exactly as it lies in HBM, and the P.V MFMA's A operand (V^T: rows = features, k = keys)
+//     is read with ds_read_b64_tr_b16: a 16-lane group reads a [4 keys][16 features] block and every lane receives
+//     the 4 keys of ITS feature.  The 4-key runs it delivers (keys 4hi..4hi+3 and 8+4hi..) are exactly the key order
+//     of the S^T accumulator registers, so P still goes from the QK^T accumulator into the P.V MFMA without a shuffle;
+//   * the key sequence of a problem is split over the KW wave groups of the workgroup itself (sub-tile j of 32 keys
+//     goes to group j % KW) and the KW partial results are merged through LDS in the epilogue: the parallelism of the
+//     split form without partials in HBM, without a merge launch and without any cross-workgroup protocol;
+//   * PREC: P is carried as hi + lo bf16 (two P.V MFMAs on the same V^T fragment), which removes the 2^-9 rounding of
+//     P -- the dominant error term where few keys are averaged (the reference rounds P to fp16, 2^-11, at the same
+//     point: tokenflow_utils.py:177-179 under run_tokenflow_pnp.py:220).  f16 inputs carry P as f16 (11 bits).
+// MFMA mapping as in ext_attn.hip: S^T = K Q^T (a lane owns one query and 16 of the sub-tile's 32 keys), O^T = V^T P.
+// Online softmax per 32-key sub-tile with the true running maximum (no deferred shift: P <= 1, which keeps the f16
+// form exact in range); the rescale is skipped (wave-uniform) when no query of the wave saw a new maximum.
+// Arithmetic of a (query, head) depends on KW and PREC only -- never on QW or on the grid -- so a rank reproduces the
+// single-GPU result bit for bit whenever both take this kernel with the same KW (tf_attn_fused_plan: shape-only rules
+// in TF_ATTN_NO_SPLIT mode).
+#include <type_traits>
+
+#include "attn_fused.h"
+
+namespace {
+
+typedef __bf16 bf16x4_vs __attribute__((__vector_size__(8)));
+typedef __fp16 fp16x4_vs __attribute__((__vector_size__(8)));
+#define TF_LDS_AS __attribute__((address_space(3)))
+
+// ds_read_b64_tr_b16: within a 16-lane group, lane i passes the address of block[i >> 2][4 * (i & 3) .. +3] of a
+// [4][16] block of 16-bit elements and receives block[0..3][i]  (cdna_hip_programming.md T10)
+template <typename T>
+struct TrRead;
+template <>
+struct TrRead<BF16> {
+    static __device__ __forceinline__ u32x2 rd(const __bf16* p) {
+        return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((TF_LDS_AS bf16x4_vs*)(p)));
+    }
+};
+template <>
+struct TrRead<F16> {
+    static __device__ __forceinline__ u32x2 rd(const _Float16* p) {
+        return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((TF_LDS_AS fp16x4_vs*)(p)));
+    }
+};
+
+template <int DH>
+struct FusedCfg {
+    static constexpr int KS = (DH + 15) / 16;    // QK^T k-steps over the head dim
+    static constexpr int DKP = KS * 16;
+    static constexpr int KROW = DKP + 8;         // K row stride in LDS (elements): an odd number of 16-B slots
+    static constexpr int MT = (DH + 31) / 32;    // P.V M-tiles over the head dim
+    // V row stride (elements).  The transpose read serves 32 lanes per LDS cycle: 4 rows x 64 B; they fall on disjoint
+    // bank ranges when the row stride is 64 or 192 (mod 256) bytes.
+    static constexpr int VS = DH == 160 ? 160 : 96;
+    static constexpr int VTROW = 40;             // (development form) V^T image [MT*32][32 keys + 8]
+    static constexpr int PPR = DH / 8;           // 16-B pieces per K / V row
+    static constexpr int K_ELEMS = 32 * KROW;
+    static_assert(VS >= MT * 32, "a transpose read must stay inside its V row");
+    static_assert((VS * 2) % 256 == 64 || (VS * 2) % 256 == 192, "bank-conflict-free transpose reads");
+};
+
+struct FusedSet {   // device form of TfAttnSet
+    const void* q;
+    const void* k;
+    const void* v;
+    void* out;
+    int64_t q_bs, q_fs, ld_q, k_bs, k_fs, v_bs, v_fs, ld, o_bs, o_fs;
+    int H, Kq, q_frame0, Kb, b0, nb, n_wg, pad_;
+};
+
+struct FusedParams {
+    FusedSet set[2];
+    int n_sets, S, nQT, tpf;   // nQT = query tiles per frame, tpf = 32-key sub-tiles per frame
+    unsigned tpf_magic;        // j / tpf = umulhi(j, tpf_magic) for tpf > 1
+    int inject, out_f32;
+    float c;                   // scale * log2(e)
+};
+
+__device__ __forceinline__ float max_xor32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+__device__ __forceinline__ int swap23(int x) { return (x & ~12) | ((x & 4) << 1) | ((x & 8) >> 1); }
+
+template <typename E, typename V4>
+__device__ __forceinline__ void store_out4(void* out, int64_t elem_off, f32x4 x, int out_f32) {
+    if (out_f32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + elem_off) = x;
+    } else {
+        V4 w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (E)x[i];
+        *reinterpret_cast<u32x2*>(reinterpret_cast<E*>(out) + elem_off) = __builtin_bit_cast(u32x2, w);
+    }
+}
+
+// QW   query waves per workgroup: the workgroup covers 32*QW queries of one (branch, frame, head)
+// KW   key groups: sub-tile j (32 keys) of the problem's key sequence is computed by the waves of group j % KW
+// PREC P as hi + lo (bf16 only)
+// TRV  V row-major in LDS + transpose reads (the product form); false: V^T image built by 2-byte LDS writes
+template <typename T, int DH, int QW, int KW, bool PREC, bool TRV>
+__global__ __launch_bounds__(64 * QW * KW, 1) void ext_attn_fused_kernel(FusedParams p) {
+    typedef FusedCfg<DH> C;
+    typedef typename T::elem E;
+    typedef typename T::vec8 vec8;
+    typedef typename T::vec4 vec4;
+    constexpr int NW = QW * KW, NT = 64 * NW;
+    constexpr int SLOT_PIECES = 32 * C::PPR;                    // 16-B pieces of K (and of V) per sub-tile
+    constexpr int NP = (KW * SLOT_PIECES + NT - 1) / NT;        // pieces of K (and of V) per thread and iteration
+    constexpr int V_ELEMS = TRV ? 32 * C::VS : C::MT * 32 * C::VTROW;
+    constexpr int SLOT_ELEMS = C::K_ELEMS + V_ELEMS;
+    constexpr int STAGE_BYTES = KW * SLOT_ELEMS * 2;
+    constexpr int MERGE_BYTES = KW > 1 ? 2 * NW * 16 * 64 * 4 + NW * 64 * 4 : 0;   // two O tile buffers + (m, l) rows
+    constexpr int LDS_BYTES = STAGE_BYTES > MERGE_BYTES ? STAGE_BYTES : MERGE_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    E* lds = reinterpret_cast<E*>(smem);
+    auto sK = [&](int slot) { return lds + slot * SLOT_ELEMS; };
+    auto sV = [&](int slot) { return lds + slot * SLOT_ELEMS + C::K_ELEMS; };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qw = wave / KW, kw = wave % KW;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int S = p.S;
+
+    // ---- problem decode: sets in order (the long bank problems of set 0 first), head fastest (H = 8: one head per XCD)
+    int u = blockIdx.x;
+    int si = 0;
+    if (p.n_sets > 1 && u >= p.set[0].n_wg) {
+        u -= p.set[0].n_wg;
+        si = 1;
+    }
+    const FusedSet& st = p.set[si];
+    const int H = st.H;
+    const int h = u % H;
+    u /= H;
+    const int qt = u % p.nQT;
+    u /= p.nQT;
+    const int f = u % st.Kq;
+    const int bi = u / st.Kq;
+    // a full set (source + two bank branches) runs its bank branches first
+    const int b = (st.b0 == 0 && st.nb == 3) ? (bi == 2 ? 0 : bi + 1) : st.b0 + bi;
+    const int bq = (p.inject && b > 0) ? 0 : b;   // branch whose q and k are used (tokenflow_utils.py:124-130)
+    const int f_lo = b == 0 ? st.q_frame0 + f : 0;
+    const int n_fr = b == 0 ? 1 : st.Kb;
+    const int tpf = p.tpf;
+    const int nst = n_fr * tpf;                   // sub-tiles of this problem
+    const int nit = (nst + KW - 1) / KW;
+
+    const E* kg = reinterpret_cast<const E*>(st.k) + bq * st.k_bs + f_lo * st.k_fs + h * DH;
+    const E* vg = reinterpret_cast<const E*>(st.v) + b * st.v_bs + f_lo * st.v_fs + h * DH;
+    const int64_t k_fs = st.k_fs, v_fs = st.v_fs, ld = st.ld;
+
+    // ---- LDS: zero once (the K pad columns DH..DKP-1 must be zero; everything else is staged before it is read, the
+    //      zero fill only makes the never-stored accumulator rows deterministic)
+    for (int id = tid; id < STAGE_BYTES / 16; id += NT) st16(smem + id * 16, u32x4{0, 0, 0, 0});
+
+    // ---- Q fragments (B operand of S^T = K Q^T), resident for the whole kernel
+    const int q_row = qt * (32 * QW) + qw * 32 + l31;
+    const bool q_ok = q_row < S;
+    vec8 qf[C::KS];
+    {
+        const E* qp = reinterpret_cast<const E*>(st.q) + bq * st.q_bs + f * st.q_fs +
+                      (int64_t)(q_ok ? q_row : S - 1) * st.ld_q + h * DH;
+#pragma unroll
+        for (int t = 0; t < C::KS; ++t) {
+            const int col = 16 * t + 8 * hi;
+            qf[t] = __builtin_bit_cast(vec8, col < DH ? ld16(qp + col) : u32x4{0, 0, 0, 0});
+        }
+    }
+
+    // ---- staging: piece -> (slot, key row, column) is fixed per thread; an iteration only moves the sub-tile index
+    u32x4 rk[NP], rv[NP];
+    int s_slot[NP], s_row[NP], s_col[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int id = min(tid + NT * i, KW * SLOT_PIECES - 1);
+        s_slot[i] = id / SLOT_PIECES;
+        const int rem = id - s_slot[i] * SLOT_PIECES;
+        s_row[i] = rem / C::PPR;
+        s_col[i] = (rem - s_row[i] * C::PPR) * 8;
+    }
+    auto sub_tile = [&](int j, int& fr, int& tt) {   // sub-tile j -> (frame of the problem's sequence, tile in frame)
+        fr = tpf == 1 ? j : (int)__umulhi((unsigned)j, p.tpf_magic);
+        tt = j - fr * tpf;
+    };
+    // branch-free loads: a piece without a sub-tile (past the end of the sequence) or a key row past S re-loads valid
+    // data (clamped indices); such keys are masked / never computed
+    auto stage_load = [&](int it) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int j = min(it * KW + s_slot[i], nst - 1);
+            int fr, tt;
+            sub_tile(j, fr, tt);
+            const int key = min(tt * 32 + s_row[i], S - 1);
+            rk[i] = ld16(kg + fr * k_fs + key * ld + s_col[i]);
+            rv[i] = ld16(vg + fr * v_fs + key * ld + s_col[i]);
+        }
+    };
+    auto stage_write = [&]() {
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            if (tid + NT * i < KW * SLOT_PIECES) {
+                st16(sK(s_slot[i]) + s_row[i] * C::KROW + s_col[i], rk[i]);
+                if constexpr (TRV) {
+                    st16(sV(s_slot[i]) + s_row[i] * C::VS + s_col[i], rv[i]);
+                } else {   // V^T image: feature row, key position = S^T accumulator order (swap23)
+                    const vec8 x = __builtin_bit_cast(vec8, rv[i]);
+                    E* dst = sV(s_slot[i]) + s_col[i] * C::VTROW + swap23(s_row[i]);
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) dst[jj * C::VTROW] = x[jj];
+                }
+            }
+    };
+
+    f32x16 o[C::MT];
+    float m_run = -INFINITY;   // running maximum of the raw scores of this wave's sub-tiles
+    float l_run = 0.f;         // this lane's share of the denominator
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[mt][r] = 0.f;
+    const float c = p.c;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // fragment addresses inside this wave's slot
+    const E* kfrag = sK(kw) + l31 * C::KROW + 8 * hi;
+    // transpose read: 16-lane group g = lane >> 4 covers features 16*(g & 1) .. +15 of the M-tile and -- lane half
+    // hi = g >> 1 -- keys 4hi .. 4hi+3 (+8 for the second read) of the 16-key k-step; lane i passes the address of
+    // block[i >> 2][4 * (i & 3)]
+    const int li = lane & 15, lg = lane >> 4;
+    const E* vtr = sV(kw) + (4 * hi + (li >> 2)) * C::VS + 16 * (lg & 1) + 4 * (li & 3);
+    const E* vtw = sV(kw) + l31 * C::VTROW + 8 * hi;   // (development form) V^T image row of this lane
+
+    stage_load(0);
+    __syncthreads();   // zero fill complete before the first staging write
+
+    for (int it = 0; it < nit; ++it) {
+        stage_write();
+        __syncthreads();                        // sub-tiles of this iteration visible
+        if (it + 1 < nit) stage_load(it + 1);   // next iteration's loads fly under the MFMAs
+
+        const int j = it * KW + kw;
+        if (j < nst) {
+            int fr, tt;
+            sub_tile(j, fr, tt);
+            const int key0 = tt * 32;
+            // ---- S^T = K Q^T
+            f32x16 s = zero;
+#pragma unroll
+            for (int t = 0; t < C::KS; ++t) s = T::mfma32(__builtin_bit_cast(vec8, ld16(kfrag + 16 * t)), qf[t], s);
+            if (key0 + 32 > S) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key0 + cd_row(r, hi) >= S) s[r] = -INFINITY;
+            }
+            // ---- online softmax (lane-local; the two lanes of a query share the maximum)
+            float mx = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            mx = max_xor32(mx);
+            if (__any(mx > m_run)) {
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);   // exp2(-inf) = 0 on the first sub-tile
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
+            }
+            const float mc = m_run * c;
+            vec8 ph[2], pl[2];   // P of the two 16-key k-steps: registers 0-7 / 8-15 of the accumulator
+            float lsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mc));
+                lsum += pr;
+                const E e = (E)pr;
+                ph[r >> 3][r & 7] = e;
+                if constexpr (PREC) pl[r >> 3][r & 7] = (E)(pr - (float)e);
+            }
+            l_run += lsum;
+            // ---- O^T += V^T P
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < C::MT; ++mt) {
+                    vec8 a;
+                    if constexpr (TRV) {
+                        const u32x2 a0 = TrRead<T>::rd(vtr + (16 * ks) * C::VS + mt * 32);
+                        const u32x2 a1 = TrRead<T>::rd(vtr + (16 * ks + 8) * C::VS + mt * 32);
+                        a = __builtin_bit_cast(vec8, u32x4{a0[0], a0[1], a1[0], a1[1]});
+                    } else {
+                        a = __builtin_bit_cast(vec8, ld16(vtw + mt * 32 * C::VTROW + 16 * ks));
+                    }
+                    o[mt] = T::mfma32(a, ph[ks], o[mt]);
+                    if constexpr (PREC) o[mt] = T::mfma32(a, pl[ks], o[mt]);
+                }
+        }
+        __syncthreads();   // every wave is done with this iteration's sub-tiles
+    }
+
+    // ---- epilogue
+    const float l_wave = l_run + __shfl_xor(l_run, 32);   // both lanes of a query: the wave's denominator
+    const int64_t out_row = b * st.o_bs + f * st.o_fs + (int64_t)q_row * (H * DH) + h * DH;
+    auto store_tile = [&](int mt, const f32x16& acc, float inv_l) {
+        if (!q_ok) return;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int d0 = mt * 32 + 8 * rg + 4 * hi;
+            if (d0 < DH) {
+                f32x4 w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = acc[rg * 4 + i] * inv_l;
+                store_out4<E, vec4>(st.out, out_row + d0, w, p.out_f32);
+            }
+        }
+    };
+    if constexpr (KW == 1) {
+        const float inv_l = 1.0f / l_wave;
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) store_tile(mt, o[mt], inv_l);
+    } else {
+        // merge the KW key groups of every query wave through LDS (the staging area is free: last barrier passed).
+        // Group order of the sums is fixed (k = 0 .. KW-1), so the result does not depend on timing.
+        float* stat = reinterpret_cast<float*>(smem + 2 * NW * 16 * 64 * 4);   // [NW][32] m, l interleaved by lane half
+        float* tile = reinterpret_cast<float*>(smem);                         // [2][NW][16][64]
+        stat[wave * 64 + lane] = hi == 0 ? m_run : l_wave;
+        __syncthreads();
+        float M = -INFINITY;
+#pragma unroll
+        for (int k2 = 0; k2 < KW; ++k2) M = fmaxf(M, stat[(qw * KW + k2) * 64 + l31]);
+        float L = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < KW; ++k2) {
+            const float mk = stat[(qw * KW + k2) * 64 + l31], lk = stat[(qw * KW + k2) * 64 + 32 + l31];
+            L = fmaf(lk, __builtin_amdgcn_exp2f((mk - M) * c), L);   // an idle group has m = -inf, l = 0: weight 0
+        }
+        const float w_own = __builtin_amdgcn_exp2f((m_run - M) * c);
+        const float inv_l = 1.0f / L;
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+            float* buf = tile + (mt & 1) * (NW * 16 * 64);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) buf[(wave * 16 + r) * 64 + lane] = o[mt][r] * w_own;
+            __syncthreads();   // round mt written; the sums of round mt-1 (other buffer) are complete by program order
+            if (mt % KW == kw) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float a = buf[((qw * KW) * 16 + r) * 64 + lane];
+#pragma unroll
+                    for (int k2 = 1; k2 < KW; ++k2) a += buf[((qw * KW + k2) * 16 + r) * 64 + lane];
+                    acc[r] = a;
+                }
+                store_tile(mt, acc, inv_l);
+            }
+        }
+    }
+}
+
+template <typename T, int DH, int QW, int KW, bool PREC, bool TRV>
+int launch_fused(const FusedParams& p, unsigned grid, hipStream_t st) {
+    typedef FusedCfg<DH> C;
+    constexpr int NW = QW * KW;
+    constexpr int V_ELEMS = TRV ? 32 * C::VS : C::MT * 32 * C::VTROW;
+    constexpr int STAGE_BYTES = KW * (C::K_ELEMS + V_ELEMS) * 2;
+    constexpr int MERGE_BYTES = KW > 1 ? 2 * NW * 16 * 64 * 4 + NW * 64 * 4 : 0;
+    constexpr int lds = STAGE_BYTES > MERGE_BYTES ? STAGE_BYTES : MERGE_BYTES;
+    auto kern = ext_attn_fused_kernel<T, DH, QW, KW, PREC, TRV>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, p);
+    TF_LAUNCH_CHECK("tf_ext_attn_fwd(fused)");
+    return 0;
+}
+
+template <typename T, int DH, bool PREC, bool TRV>
+int dispatch_geom(const FusedParams& p, unsigned grid, int qw, int kw, hipStream_t st) {
+    if (qw == 1 && kw == 4) return launch_fused<T, DH, 1, 4, PREC, TRV>(p, grid, st);
+    if (qw == 2 && kw == 4) return launch_fused<T, DH, 2, 4, PREC, TRV>(p, grid, st);
+    if (qw == 4 && kw == 2) return launch_fused<T, DH, 4, 2, PREC, TRV>(p, grid, st);
+    if (qw == 4 && kw == 1) return launch_fused<T, DH, 4, 1, PREC, TRV>(p, grid, st);
+    tf_set_error("tf_ext_attn_fwd(fused): geometry (%d query waves, %d key groups) is not built", qw, kw);
+    return TF_ERR_SHAPE;
+}
+
+template <typename T, int DH>
+int dispatch_prec(const FusedParams& p, unsigned grid, const TfFusedPlan& plan, hipStream_t st) {
+    constexpr bool bf = std::is_same<T, BF16>::value;
+    if (plan.vtw) {
+#ifdef TF_FUSED_WITH_VT_WRITE
+        if (bf && plan.prec) return dispatch_geom<T, DH, bf, false>(p, grid, plan.qw, plan.kw, st);
+        return dispatch_geom<T, DH, false, false>(p, grid, plan.qw, plan.kw, st);
+#else
+        tf_set_error("tf_ext_attn_fwd(fused): the transposing-write form is a development build option");
+        return TF_ERR_SHAPE;
+#endif
+    }
+    if (bf && plan.prec) return dispatch_geom<T, DH, bf, true>(p, grid, plan.qw, plan.kw, st);
+    return dispatch_geom<T, DH, false, true>(p, grid, plan.qw, plan.kw, st);
+}
+
+template <typename T>
+int dispatch_dh(int Dh, const FusedParams& p, unsigned grid, const TfFusedPlan& plan, hipStream_t st) {
+    switch (Dh) {
+        case 40: return dispatch_prec<T, 40>(p, grid, plan, st);
+        case 64: return dispatch_prec<T, 64>(p, grid, plan, st);
+        case 80: return dispatch_prec<T, 80>(p, grid, plan, st);
+        case 160: return dispatch_prec<T, 160>(p, grid, plan, st);
+    }
+    return TF_ERR_SHAPE;
+}
+
+int64_t n_problems(const TfAttnSet* sets, int n_sets) {
+    int64_t n = 0;
+    for (int i = 0; i < n_sets; ++i) n += (int64_t)sets[i].nb * sets[i].Kq * sets[i].H;
+    return n;
+}
+
+}  // namespace
+
+// Which calls take the fused kernel, and in which geometry.
+//   * KW (the in-workgroup key split) and PREC change the arithmetic of a (query, head); QW and the grid do not.
+//   * shape rule (any mode): S <= 256 -> KW = 4.  A function of (S, Dh, bank frames) only, so a sharded rank and the
+//     single GPU agree and TF_ATTN_NO_SPLIT results stay bit-identical across grid sizes.
+//   * grid rule (only without TF_ATTN_NO_SPLIT): S <= 1024 and a grid of at most FUSED_MAX_QWAVES 32-query waves (a
+//     sharded rank's level 1, BASELINE config 1 level 0) -> KW = 4.
+//   * PREC: bf16 and S <= 256 (shape only, and independent of which branches a call computes: the parts of a
+//     sharded rank's pass must round exactly as the single-GPU call does).
+//   * QW: 2 query waves per workgroup (a staged sub-tile is shared by two waves) while that leaves >= 256 workgroups.
+#ifndef TF_TUNE_FUSED_MAX_QWAVES
+#define TF_TUNE_FUSED_MAX_QWAVES 3072
+#endif
+TfFusedPlan tf_attn_fused_plan(const TfAttnSet* sets, int n_sets, int S, int Dh, int dtype, int flags) {
+    TfFusedPlan pl{};
+    if (flags & TF_ATTN_NO_FUSED) return pl;
+    if (!(Dh == 40 || Dh == 64 || Dh == 80 || Dh == 160) || (dtype != TF_BF16 && dtype != TF_F16)) return pl;
+    if (flags & TF_ATTN_FOLD_SCALE) return pl;   // the folded-scale opt-in is a Dh = 40 streaming-kernel form
+    const int64_t n_prob = n_problems(sets, n_sets);
+    const int64_t qwaves = n_prob * ((S + 31) / 32);
+    const bool forced = (flags & TF_ATTN_FUSED) != 0;
+    const bool shape_rule = S <= 256;
+    const bool grid_rule = !(flags & TF_ATTN_NO_SPLIT) && S <= 1024 && qwaves <= TF_TUNE_FUSED_MAX_QWAVES;
+    if (!forced && !shape_rule && !grid_rule) return pl;
+    pl.use = 1;
+    pl.kw = 4;
+    pl.qw = n_prob * ((S + 63) / 64) >= 256 ? 2 : 1;
+    pl.prec = dtype == TF_BF16 && S <= 256;
+    // hints (development / A-B measurements; 0 = automatic)
+    const int hq = (flags >> 8) & 7, hk = (flags >> 11) & 7;
+    if (hq) pl.qw = 1 << (hq - 1);
+    if (hk) pl.kw = 1 << (hk - 1);
+    if (flags & TF_ATTN_PRECISE_P) pl.prec = dtype == TF_BF16;
+    if (flags & TF_ATTN_NO_PRECISE_P) pl.prec = 0;
+    pl.vtw = (flags & TF_ATTN_HINT_VT_WRITE) ? 1 : 0;
+    return pl;
+}
+
+int tf_attn_fused_launch(const TfAttnSet* sets, int n_sets, int S, int Dh, float scale, int flags, int dtype,
+                         const TfFusedPlan& plan, hipStream_t st) {
+    TF_ARG(sets && n_sets >= 1 && n_sets <= 2, TF_ERR_SHAPE, "tf_ext_attn_fwd(fused): %d tensor sets", n_sets);
+    FusedParams p{};
+    p.n_sets = n_sets;
+    p.S = S;
+    p.nQT = (S + 32 * plan.qw - 1) / (32 * plan.qw);
+    p.tpf = (S + 31) / 32;
+    p.tpf_magic = p.tpf > 1 ? (unsigned)(((uint64_t)1 << 32) / (unsigned)p.tpf + 1) : 0u;
+    p.inject = (flags & TF_ATTN_INJECT) ? 1 : 0;
+    p.out_f32 = (flags & TF_ATTN_OUT_F32) ? 1 : 0;
+    p.c = (float)((double)scale * 1.4426950408889634);
+    int64_t grid = 0;
+    for (int i = 0; i < n_sets; ++i) {
+        const TfAttnSet& a = sets[i];
+        FusedSet& d = p.set[i];
+        TF_ARG(a.q && a.k && a.v && a.out, TF_ERR_NULL, "tf_ext_attn_fwd(fused): null pointer in set %d", i);
+        TF_ARG(a.H > 0 && a.Kq > 0 && a.Kb > 0 && a.nb >= 1 && a.b0 >= 0 && a.b0 + a.nb <= 3 && a.q_frame0 >= 0,
+               TF_ERR_SHAPE, "tf_ext_attn_fwd(fused): set %d: H=%d Kq=%d Kb=%d branches [%d, %d)", i, a.H, a.Kq, a.Kb, a.b0,
+               a.b0 + a.nb);
+        d.q = a.q, d.k = a.k, d.v = a.v, d.out = a.out;
+        d.q_bs = a.q_bs, d.q_fs = a.q_fs, d.ld_q = a.ld_q, d.k_bs = a.k_bs, d.k_fs = a.k_fs, d.v_bs = a.v_bs, d.v_fs = a.v_fs;
+        d.ld = a.ld, d.o_bs = a.o_bs, d.o_fs = a.o_fs;
+        d.H = a.H, d.Kq = a.Kq, d.q_frame0 = a.q_frame0, d.Kb = a.Kb, d.b0 = a.b0, d.nb = a.nb;
+        d.n_wg = a.nb * a.Kq * a.H * p.nQT;
+        grid += d.n_wg;
+    }
+    TF_ARG(grid > 0 && grid < ((int64_t)1 << 31), TF_ERR_SHAPE, "tf_ext_attn_fwd(fused): grid of %lld workgroups",
+           (long long)grid);
+    // the magic division is exact for j * tpf < 2^32: the sub-tile index stays far below that
+    return dtype == TF_BF16 ? dispatch_dh<BF16>(Dh, p, (unsigned)grid, plan, st)
+                            : dispatch_dh<F16>(Dh, p, (unsigned)grid, plan, st);
+}

@@ -16,6 +16,7 @@
 // events; no host synchronisation anywhere.
 #include <new>
 
+#include "attn_fused.h"
 #include "tf_common.h"
 
 struct tf_comm;   // csrc/comm.hip
@@ -231,34 +232,50 @@ extern "C" int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const 
             fss[0] = fss[1] = q_fs, fss[2] = fss[3] = k_fs, fss[4] = fss[5] = v_fs;
         }
         if (const int rc = tf_head_pack(slabs, fss, ns, send, W, Kl, S, (int)hd, ld, 2, stream)) return rc;
+        // ---- the two tensor sets of the attention: the bank branches on this rank's head group over all K frames, read
+        //      from `recv` and written to `send2` in place (both laid out for the collectives), and the source branch of
+        //      the local frames on the local projections.
+        const int64_t fs_r = ns * Shd;          // frame stride of recv [K][ns][S][hd]
+        // base such that branch b sits at base + b * Shd (the strided entry point's convention): a bank-only call
+        // never touches branch 0, so the base may lie one slab in front of the buffer -- formed as an integer
+        auto slab = [&](const E* buf, int64_t first_slab, int first_branch) {
+            return reinterpret_cast<const E*>(reinterpret_cast<uintptr_t>(buf) +
+                                              (uintptr_t)((first_slab - first_branch) * Shd * (int64_t)sizeof(E)));
+        };
+        const E *qb, *kb, *vb;
+        if (inject)    // slabs [q0, k0, v1, v2]
+            qb = slab(recv, 0, 0), kb = slab(recv, 1, 0), vb = slab(recv, 2, 1);
+        else           // slabs [q1, q2, k1, k2, v1, v2]
+            qb = slab(recv, 0, 1), kb = slab(recv, 2, 1), vb = slab(recv, 4, 1);
+        E* ob = const_cast<E*>(slab(send2, 0, 1));                           // send2 [K][uncond|cond][S][hd]
+        TfAttnSet sets[2] = {};
+        sets[0].q = qb, sets[0].k = kb, sets[0].v = vb, sets[0].out = ob;
+        sets[0].q_bs = Shd, sets[0].q_fs = fs_r, sets[0].ld_q = hd, sets[0].k_bs = Shd, sets[0].k_fs = fs_r;
+        sets[0].v_bs = Shd, sets[0].v_fs = fs_r, sets[0].ld = hd, sets[0].o_bs = Shd, sets[0].o_fs = 2 * Shd;
+        sets[0].H = Hl, sets[0].Kq = K, sets[0].q_frame0 = 0, sets[0].Kb = K, sets[0].b0 = 1, sets[0].nb = 2;
+        sets[1].q = q, sets[1].k = k, sets[1].v = v, sets[1].out = out_loc;
+        sets[1].q_bs = q_bs, sets[1].q_fs = q_fs, sets[1].ld_q = ld_q, sets[1].k_bs = k_bs, sets[1].k_fs = k_fs;
+        sets[1].v_bs = v_bs, sets[1].v_fs = v_fs, sets[1].ld = ld, sets[1].o_bs = o_bs, sets[1].o_fs = SD;
+        sets[1].H = H, sets[1].Kq = Kl, sets[1].q_frame0 = 0, sets[1].Kb = Kl, sets[1].b0 = 0, sets[1].nb = 1;
+        // small problems (the coarse levels, a rank's share of the middle ones): ONE launch for both sets behind the
+        // exchange -- no V^T pre-passes, no split + merge pair, no separate source launch (csrc/ext_attn_fused.hip)
+        const TfFusedPlan plan = tf_attn_fused_plan(sets, 2, S, Dh, dtype, flags);
         // ---- first all-to-all (exchange stream) and, under it, the source branch of the local frames
         if (const int rc = order(rk, st, rk->xs, "tf_rank_pivotal")) return rc;
         if (const int rc = tf_all_to_all_rows(rk->comm, send, recv, own, cnt, ns * Shd, dtype, rk->xs)) return rc;
         hipEvent_t arrived = rk->next();
         TF_HIP(hipEventRecord(arrived, rk->xs), "tf_rank_pivotal");
-        {
+        if (!plan.use) {
             const int64_t strides[9] = {q_bs, q_fs, k_bs, k_fs, v_bs, v_fs, o_bs, SD, ld_q};
             if (const int rc = tf_ext_attn_fwd_strided(q, k, v, out_loc, Kl, Kl, 0, S, H, Dh, ld, strides, scale,
                                                        flags | TF_ATTN_SOURCE_ONLY, dtype, wsb + L.ws_src, L.ws_src_bytes,
                                                        stream))
                 return rc;
         }
-        // ---- bank branches on this rank's head group, all K frames: read `recv`, write `send2`, both in place
         TF_HIP(hipStreamWaitEvent(st, arrived, 0), "tf_rank_pivotal");
-        {
-            const int64_t fs_r = ns * Shd;          // frame stride of recv [K][ns][S][hd]
-            // base such that branch b sits at base + b * Shd (the strided entry point's convention): a bank-only call
-            // never touches branch 0, so the base may lie one slab in front of the buffer -- formed as an integer
-            auto slab = [&](const E* buf, int64_t first_slab, int first_branch) {
-                return reinterpret_cast<const E*>(reinterpret_cast<uintptr_t>(buf) +
-                                                  (uintptr_t)((first_slab - first_branch) * Shd * (int64_t)sizeof(E)));
-            };
-            const E *qb, *kb, *vb;
-            if (inject)    // slabs [q0, k0, v1, v2]
-                qb = slab(recv, 0, 0), kb = slab(recv, 1, 0), vb = slab(recv, 2, 1);
-            else           // slabs [q1, q2, k1, k2, v1, v2]
-                qb = slab(recv, 0, 1), kb = slab(recv, 2, 1), vb = slab(recv, 4, 1);
-            E* ob = const_cast<E*>(slab(send2, 0, 1));                           // send2 [K][uncond|cond][S][hd]
+        if (plan.use) {
+            if (const int rc = tf_attn_fused_launch(sets, 2, S, Dh, scale, flags, dtype, plan, st)) return rc;
+        } else {
             const int64_t strides[9] = {Shd, fs_r, Shd, fs_r, Shd, fs_r, Shd, 2 * Shd, hd};
             if (const int rc = tf_ext_attn_fwd_strided(qb, kb, vb, ob, K, K, 0, S, Hl, Dh, hd, strides, scale,
                                                        flags | TF_ATTN_BANK_ONLY, dtype, wsb + L.ws_bank, L.ws_bank_bytes,

@@ -92,7 +92,8 @@ NO_SPLIT = os.environ.get("TOKENFLOW_ATTN_NO_SPLIT", "0") not in ("", "0")
 def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float,
              inject: bool, out: Optional[torch.Tensor] = None, q_frame0: int = 0,
              fold_scale: Optional[bool] = None, part: str = "all",
-             out_dtype: Optional[torch.dtype] = None, no_split: Optional[bool] = None) -> torch.Tensor:
+             out_dtype: Optional[torch.dtype] = None, no_split: Optional[bool] = None,
+             fused: Optional[bool] = None, hints: int = 0) -> torch.Tensor:
     """Extended attention core (tokenflow_utils.py:124-197).  k,v: [3K,S,D] bf16/f16 (the bank),
     q: [3Kq,S,D] = the queries of keyframes q_frame0..q_frame0+Kq-1 (Kq = K on one GPU); last dim
     contiguous, equal token stride (q, k, v may be column slabs of one fused projection output).
@@ -101,7 +102,10 @@ def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scal
     part = "bank": only the uncond/cond branches are computed (the source slabs of v and out, and those
     of q, k that the call does not read, are never touched); part = "source": only the source branch.
     no_split: True = one pass per bank problem whatever the grid (TF_ATTN_NO_SPLIT: arithmetic independent of the
-    grid size), False = let small grids split the bank over workgroups and merge; None = the module default."""
+    grid size), False = let small grids split the bank over workgroups and merge; None = the module default.
+    fused: None = the library decides (small problems run in ONE fused launch, csrc/ext_attn_fused.hip), False = the
+    streaming kernels at every size (TF_ATTN_NO_FUSED), True = the fused kernel at any size it is built for;
+    hints: further TF_ATTN_* bits (_lib.attn_hint, TF_ATTN_PRECISE_P ...; measurements and tests)."""
     dev = _need_gpu(q, k, v, out)
     lib = _lib.load()
     B, S, D = k.shape
@@ -136,6 +140,7 @@ def ext_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scal
     flags |= {"all": 0, "bank": _lib.TF_ATTN_BANK_ONLY, "source": _lib.TF_ATTN_SOURCE_ONLY}[part]
     if NO_SPLIT if no_split is None else no_split:
         flags |= _lib.TF_ATTN_NO_SPLIT
+    flags |= int(hints) | (0 if fused is None else _lib.TF_ATTN_FUSED if fused else _lib.TF_ATTN_NO_FUSED)
     key = (K, S, heads, dh, dt)
     nbytes = _attn_ws_bytes.get(key)
     if nbytes is None:
@@ -158,7 +163,7 @@ def _view_base(t: torch.Tensor, b0: int, S: int, what: str):
 def ext_attn_views(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, heads: int, scale: float,
                    inject: bool, part: str = "all", branch0=(0, 0, 0, 0), q_frame0: int = 0,
                    fold_scale: Optional[bool] = None, no_split: Optional[bool] = None,
-                   stream: Optional[int] = None) -> torch.Tensor:
+                   stream: Optional[int] = None, fused: Optional[bool] = None, hints: int = 0) -> torch.Tensor:
     """`ext_attn` on strided 4-D views [branches, frames, S, D] (tf_ext_attn_fwd_strided): q, k, v are read where
     a collective left them and `out` is written where the next one sends from -- no re-layout copies.  Each view
     holds the branches `branch0[i] ..` of its tensor (q, k, v, out in that order; e.g. a bank-only call passes the
@@ -187,6 +192,7 @@ def ext_attn_views(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch
         flags |= _lib.TF_ATTN_NO_SPLIT
     if out.dtype == torch.float32:
         flags |= _lib.TF_ATTN_OUT_F32
+    flags |= int(hints) | (0 if fused is None else _lib.TF_ATTN_FUSED if fused else _lib.TF_ATTN_NO_FUSED)
     key = (K, S, heads, dh, dt)
     nbytes = _attn_ws_bytes.get(key)
     if nbytes is None:

@@ -1,0 +1,28 @@
+#!/bin/bash
+# One parameterised driver for the round's gpurun calls (run from the repository root on the GPU box):
+#   tools/gpu_session.sh <out-dir-name> <stage> [<stage> ...]
+# Stages write into gpurun_out/<out-dir-name>/; every stage is wrapped in its own timeout.
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+O=gpurun_out/$1; shift
+mkdir -p "$O"
+for stage in "$@"; do
+  echo "=== stage $stage $(date +%T)"
+  case $stage in
+    trprobe)    timeout 60 tools/ubench/tr_probe > $O/tr_probe.txt 2>&1; cat $O/tr_probe.txt ;;
+    fusedtests) timeout 900 python -m pytest tests/test_fused_attn_gpu.py -q --tb=line -p no:cacheprovider 2>&1 | tail -40 > $O/fused_tests.txt; tail -25 $O/fused_tests.txt ;;
+    kerneltests) timeout 1500 python -m pytest tests/test_kernels_gpu.py -q --tb=line -p no:cacheprovider -k "attn" 2>&1 | tail -30 > $O/kernel_attn_tests.txt; tail -15 $O/kernel_attn_tests.txt ;;
+    shardtests) timeout 1500 python -m pytest tests/test_sharded_gpu.py -q --tb=short -p no:cacheprovider -x 2>&1 | tail -40 > $O/sharded_tests.txt; tail -15 $O/sharded_tests.txt ;;
+    alltests)   timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x 2>&1 | tail -40 > $O/all_gpu_tests.txt; tail -15 $O/all_gpu_tests.txt ;;
+    fusedbench) timeout 600 python tools/fused_microbench.py > $O/fused_microbench.txt 2>&1; tail -40 $O/fused_microbench.txt ;;
+    rankstep)   timeout 600 python tools/rank_step_microbench.py --native --only split,auto > $O/rank_step_native.txt 2>&1; tail -14 $O/rank_step_native.txt
+                timeout 300 python tools/rank_step_microbench.py --native --only onepass,auto > $O/rank_step_native_onepass.txt 2>&1; tail -4 $O/rank_step_native_onepass.txt | head -3 ;;
+    bench)      timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; python -c "import json;d=json.load(open('$O/bench.json'));print(d['ms_per_step'],d['value'],d['roofline']['frac'],d.get('parity',{}).get('attn_linf'),[ (l['attn_linf'],l['attn_linf_fp32_out']) for l in d.get('parity',{}).get('by_level',[])])" ;;
+    benchquick) timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-yardstick > $O/bench_quick.json 2> $O/bench_quick.err; python -c "import json;d=json.load(open('$O/bench_quick.json'));print(d['ms_per_step'],d['value'],d['roofline']['frac'],[ (l['attn_linf'],l['attn_linf_fp32_out']) for l in d.get('parity',{}).get('by_level',[])])" ;;
+    cfg1)       timeout 600 python bench.py --config cfg1 --steps 50 --warmup 10 --no-cpu-baseline --no-yardstick > $O/bench_cfg1.json 2> $O/bench_cfg1.err; python -c "import json;d=json.load(open('$O/bench_cfg1.json'));print('cfg1',d['ms_per_step'],[ (l['attn_linf'],l['attn_linf_fp32_out']) for l in d.get('parity',{}).get('by_level',[])])"
+                timeout 600 python bench.py --config cfg1 --steps 50 --warmup 10 --graph --no-cpu-baseline --no-yardstick --no-parity > $O/bench_cfg1_graph.json 2> $O/bench_cfg1_graph.err; python -c "import json;d=json.load(open('$O/bench_cfg1_graph.json'));print('cfg1 graph',d['ms_per_step'])" ;;
+    proxy)      for v in 0 1; do timeout 120 tools/ubench/attn_loop_proxy $v >> $O/attn_loop_proxy.txt 2>&1; done; cat $O/attn_loop_proxy.txt ;;
+    *) echo "unknown stage $stage" ;;
+  esac
+done
+echo "=== done $(date +%T)"
