@@ -143,8 +143,8 @@ def run_step(cfg, blocks, shard, inject_on, w, events=None, exchange=None, per_c
             # blocks, then the chunk passes.  In place: inverse norms and attention output go straight into the block's
             # halo-extended buffers, ONE grouped neighbour exchange per block (pivots, inverse norms, attention output of
             # the last local keyframe), which has the rest of the pivotal pass to arrive.
-            ops.pivot_inv_norm(blk.pivots, out=blk.ext[1][1:])
-            pending.append((blk, shard.pivotal_block(blk.q, blk.k, blk.v, blk.h, scale, inj, blk.ext, mode=exchange)))
+            pending.append((blk, shard.pivotal_block(blk.q, blk.k, blk.v, blk.h, scale, inj, blk.ext, mode=exchange,
+                                                     inv_norm=True)))
         else:
             # the pivots' halo (features + inverse norms of the last local keyframe -> rank r+1) does not depend on
             # the attention: issued first, it travels under it

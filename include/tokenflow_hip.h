@@ -48,9 +48,8 @@ extern "C" {
 #define TF_ATTN_NO_FUSED 128   /* never take the fused small-problem kernel (below): the streaming kernels at every size */
 #define TF_ATTN_FUSED (1 << 17) /* take the fused small-problem kernel at any size it is built for */
 /* tuning hints of the fused small-problem kernel (0 = automatic; A/B measurements, tools/attn_microbench.py) */
-#define TF_ATTN_HINT_QW(code) (((code) & 7) << 8)    /* code 1, 2, 3 = 1, 2, 4 query waves per workgroup */
-#define TF_ATTN_HINT_KW(code) (((code) & 7) << 11)   /* code 1, 2, 3 = 1, 2, 4 key groups per workgroup */
-#define TF_ATTN_HINT_VT_WRITE (1 << 14)              /* development builds only: V transposed by LDS writes */
+#define TF_ATTN_HINT_QW(code) (((code) & 7) << 8)    /* code 1, 2, 3 = 1 (the wave-private form), 2, 4 query waves per workgroup */
+#define TF_ATTN_HINT_KW(code) (((code) & 7) << 11)   /* code 1, 2, 3, 4 = 1, 2, 4, 8 key groups per workgroup */
 #define TF_ATTN_PRECISE_P (1 << 15)                  /* fused kernel, bf16: carry P as hi + lo whatever the size */
 #define TF_ATTN_NO_PRECISE_P (1 << 16)               /* fused kernel: P in one 16-bit value whatever the size */
 
@@ -355,6 +354,9 @@ typedef struct tf_comm_hooks {
 } tf_comm_hooks;
 int tf_comm_init_hooks(const tf_comm_hooks* hooks, int rank, int world, tf_comm** comm_out);
 int tf_comm_init_loopback(int rank, int world, tf_comm** comm_out);
+/* loopback only: enabled = 0 makes every exchange a no-op (nothing moves, nothing is enqueued) -- the rank's launch sequence
+ * with the stand-in copies taken out of the timing as well; buffers that an exchange would have filled keep their contents */
+int tf_comm_loopback_copies(tf_comm* comm, int enabled);
 int tf_comm_destroy(tf_comm* comm);
 int tf_comm_rank(const tf_comm* comm);
 int tf_comm_world(const tf_comm* comm);
@@ -401,6 +403,9 @@ int tf_sendrecv_pivot(tf_comm* comm, const void* const* send, const int64_t* sen
 #define TF_RANK_NO_HALO 16   /* or-ed into `mode`: the attention alone -- kfo_ext is a plain [3, Kl, S, H*Dh] output, piv_ext /
                                 inv_ext are not read (NULL allowed), no neighbour exchange (hosts whose cached attention
                                 output is not this one: the hook path caches it after the to_out projection) */
+#define TF_RANK_INV_NORM 32  /* or-ed into `mode`: inv_ext's local slots o.. are OUTPUTS -- the call computes 1 / ||row|| of the
+                                local pivots in piv_ext (tf_pivot_inv_norm's arithmetic, bit for bit) inside its pack launch,
+                                instead of the caller in a launch of its own */
 #define TF_RANK_SLOTS 64
 typedef struct tf_rank tf_rank;
 int tf_rank_create(tf_comm* comm, tf_comm* halo_comm, int K, tf_rank** rank_out);

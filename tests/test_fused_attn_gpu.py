@@ -7,8 +7,8 @@ Tolerances:
   * precise P (bf16, hi + lo; the default at S <= 256) with fp32 output: the rounding of P and of the output are both
     gone -- what is left is fp32 accumulation order and v_exp_f32:  |out - ref| <= 2e-5 + 2^-16 softmax.|V| ;
     with bf16 output: that plus the output's own rounding (half an ulp, 2^-9 relative);
-  * alternative forms of the SAME arithmetic (transposing LDS writes instead of ds_read_b64_tr_b16; 1 or 2 query waves
-    per workgroup; bank + source parts instead of one call): bit-identical.
+  * alternative forms of the SAME arithmetic (wave-private or shared-tile staging, 1 or 2 query waves per workgroup;
+    bank + source parts instead of one call): bit-identical.
 """
 import pytest
 import torch
@@ -35,7 +35,7 @@ SHAPES = [(2, 256, 2, 40), (3, 136, 2, 64), (2, 200, 1, 80), (1, 16, 2, 160), (4
 
 
 @pytest.mark.parametrize("K,S,h,d", SHAPES)
-@pytest.mark.parametrize("geom", [(1, 4), (2, 4), (4, 2), (4, 1)])
+@pytest.mark.parametrize("geom", [(1, 4), (1, 8), (2, 4), (4, 2), (4, 1)])
 @pytest.mark.parametrize("inject", [False, True])
 def test_fused_geometries_vs_oracle(K, S, h, d, geom, inject):
     """Every built geometry (query waves x key groups) on ragged and tiny shapes: 1-token frames, S below one sub-tile,
@@ -105,31 +105,12 @@ def test_fused_f16_meets_1e3_absolute(K, S, h, d):
         assert float(err.max()) < 1e-3
 
 
-@pytest.mark.parametrize("K,S,h,d", [(2, 256, 2, 40), (3, 136, 2, 64), (2, 200, 1, 80), (2, 45, 2, 160), (8, 256, 1, 160)])
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_fused_transpose_read_equals_transposing_write(K, S, h, d, dtype):
-    """ds_read_b64_tr_b16 on the row-major V image against the development form that transposes V with 2-byte LDS
-    writes and reads it with ds_read_b128 (the streaming kernels' proven layout): the MFMA operands are the same
-    values in the same order, so the results are bit-identical."""
-    ops, lib = _ops()
-    q, k, v = _inputs(K, S, h, d, dtype, 3000 + K + S + d)
-    dq, dk, dv = (t.to(dtype).cuda() for t in (q, k, v))
-    for geom in ((1, 4), (2, 4), (4, 1)):
-        a = ops.ext_attn(dq, dk, dv, h, d ** -0.5, True, fused=True, hints=lib.attn_hint(*geom))
-        try:
-            b = ops.ext_attn(dq, dk, dv, h, d ** -0.5, True, fused=True, hints=lib.attn_hint(*geom) | lib.TF_ATTN_HINT_VT_WRITE)
-        except lib.TokenflowHipError as e:
-            if "development build" in str(e):
-                pytest.skip("library built without TF_FUSED_WITH_VT_WRITE")
-            raise
-        assert torch.equal(a, b), f"geom {geom}: max diff {float((a.float() - b.float()).abs().max()):.3e}"
-
-
 @pytest.mark.parametrize("K,S,h,d", [(2, 256, 2, 40), (3, 136, 2, 64), (8, 256, 1, 160), (8, 1024, 1, 80), (4, 64, 8, 160)])
 def test_fused_arithmetic_independent_of_query_waves_and_parts(K, S, h, d):
-    """The arithmetic of a (query, head) depends on the number of key groups only: 1 or 2 query waves per workgroup,
-    and the bank-only + source-only parts of a sharded rank, reproduce the full call bit for bit (what keeps a rank's
-    one-pass result identical to the single-GPU one)."""
+    """The arithmetic of a (query, head) depends on the number of key groups only: the wave-private form (one query wave,
+    K fragments straight from global memory, no barriers), the shared-tile form with 2 query waves per workgroup, and
+    the bank-only + source-only parts of a sharded rank all reproduce the same bits (what keeps a rank's one-pass
+    result identical to the single-GPU one)."""
     ops, lib = _ops()
     q, k, v = _inputs(K, S, h, d, torch.bfloat16, 4000 + K + S + d)
     dq, dk, dv = (t.bfloat16().cuda() for t in (q, k, v))
@@ -160,7 +141,7 @@ def test_fused_softmax_spikes_across_key_groups(d, gain):
     q, k, v = (orc.bf16_round(x) for x in (q, k, v))
     for inject in (False, True):
         refs = attn_ref(q, k, v, h, d ** -0.5, inject, need_sigma=False)
-        for geom in ((1, 4), (4, 2)):
+        for geom in ((1, 4), (1, 8), (4, 2)):
             out = ops.ext_attn(q.bfloat16().cuda(), k.bfloat16().cuda(), v.bfloat16().cuda(), h, d ** -0.5, inject,
                                fused=True, hints=lib.attn_hint(*geom))
             assert torch.isfinite(out.float()).all()

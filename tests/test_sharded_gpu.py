@@ -12,6 +12,14 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
+def _attn_oracle_bound(q, k, v, h, d, inject):
+    """(oracle output, its parity bound) of the attention on device tensors (tests/test_kernels_gpu.py: attn_bound):
+    what the split / fused forms of a sharded rank are held to -- the ORACLE, not another HIP launch."""
+    from tests.test_kernels_gpu import attn_bound, attn_ref
+    ref, ref_abs, _ = attn_ref(q.float().cpu(), k.float().cpu(), v.float().cpu(), h, d ** -0.5, inject, need_sigma=False)
+    return ref, attn_bound(ref, ref_abs)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -64,16 +72,19 @@ def _worker(rank, world, port, K, inject, mode, no_split, ret, backend="gloo"):
         out = sh.pivotal_attention(loc(q), loc(k), loc(v), h, d ** -0.5, inject, mode=mode)
         if no_split:     # same arithmetic per (query, head) whoever computes it
             ok = torch.equal(out, loc(full))
-        else:            # small grids split the bank and merge: fp32 sums re-associated, bf16 outputs within a rounding
-            a, r = out.float(), loc(full).float()
-            ok = bool(((a - r).abs() <= 2.0 ** -7 * r.abs() + 1e-3).all())
+            slack = 0.0
+        else:            # small grids take other kernels (key split inside the workgroup, merged): against the ORACLE,
+            o_ref, o_bound = _attn_oracle_bound(q, k, v, h, d, inject)      # with the parity bound of the attention tests
+            ok = bool(((out.float().cpu() - loc(o_ref)).abs() <= loc(o_bound)).all())
+            # the propagation gathers rows of two attention outputs that are each within the bound of the oracle
+            slack = 2.0 * float(o_bound.max())
         pe, ie, ke = sh.exchange_halo(piv[f0:f0 + Kl], inv[f0:f0 + Kl], out)
 
         def same(y, r):
             if no_split:
                 return torch.equal(y, r)
-            # same indices, gathered rows within the attention tolerance above
-            return bool(((y.float() - r.float()).abs() <= 2.0 ** -6 * r.float().abs() + 2e-3).all())
+            # same indices; gathered / blended rows of attention outputs within the bound, one fp32 -> 16-bit rounding
+            return bool(((y.float() - r.float()).abs() <= 2.0 ** -8 * r.float().abs() + slack).all())
         for j in range(Kl):
             ok = ok and same(sh.propagate(j, tgt[f0 + j], res[f0 + j], pe, ie, ke, w, n), ref[f0 + j])
         # all local chunks in one call; halo in two halves with the first chunk deferred behind it
@@ -320,8 +331,10 @@ def _native_worker(rank, world, port, K, h, inject, mode, split, ret):
             for t in ext:
                 t.view(torch.int16 if t.dtype == torch.bfloat16 else torch.int32).fill_(0x7fc0 if t.dtype == torch.bfloat16 else 0x7fc00000)  # NaN
             ext[0][o:].copy_(piv[f0:f0 + Kl])
-            ops.pivot_inv_norm(ext[0][o:], out=ext[1][o:])
-            pe, ie, ke, reqs = shard.pivotal_block(loc(q), loc(k), loc(v), h, d ** -0.5, inject, ext, mode=mode)
+            if shard is py:        # the native executor computes the inverse norms inside its pack launch (TF_RANK_INV_NORM)
+                ops.pivot_inv_norm(ext[0][o:], out=ext[1][o:])
+            pe, ie, ke, reqs = shard.pivotal_block(loc(q), loc(k), loc(v), h, d ** -0.5, inject, ext, mode=mode,
+                                                   inv_norm=shard is sh)
             first, rest = shard.propagate_all(tgt_all, res_all, pe, ie, ke, w, n, halo_reqs=reqs)
             torch.cuda.synchronize()
             got = ke.view(3, Kl + o, S, D)[:, o:].reshape(3 * Kl, S, D)
@@ -330,9 +343,9 @@ def _native_worker(rank, world, port, K, h, inject, mode, split, ret):
                 ok = ok and torch.equal(got, loc(full)) and torch.equal(first, ref[f0])
                 if Kl > 1:
                     ok = ok and torch.equal(rest, want.view(3, Kl, n, S, D)[:, 1:].reshape(3 * (Kl - 1) * n, S, D))
-            else:
-                a, r = got.float(), loc(full).float()
-                ok = ok and bool(((a - r).abs() <= 2.0 ** -7 * r.abs() + 1e-3).all())
+            else:                  # against the oracle with the attention tests' bound (not against another HIP launch)
+                o_ref, o_bound = _attn_oracle_bound(q, k, v, h, d, inject)
+                ok = ok and bool(((got.float().cpu() - loc(o_ref)).abs() <= loc(o_bound)).all())
             if rank > 0:           # the halo slot holds the left neighbour's last keyframe
                 ok = ok and torch.equal(pe[0], piv[f0 - 1]) and torch.equal(ie[0], inv[f0 - 1])
                 if not split:

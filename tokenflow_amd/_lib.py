@@ -11,18 +11,18 @@ TF_ATTN_INJECT, TF_ATTN_EXACT_SCALE, TF_ATTN_BANK_ONLY, TF_ATTN_SOURCE_ONLY, TF_
 TF_ATTN_OUT_F32 = 32
 TF_ATTN_FOLD_SCALE = 64
 TF_ATTN_NO_FUSED, TF_ATTN_FUSED = 128, 1 << 17
-TF_ATTN_HINT_VT_WRITE, TF_ATTN_PRECISE_P, TF_ATTN_NO_PRECISE_P = 1 << 14, 1 << 15, 1 << 16
+TF_ATTN_PRECISE_P, TF_ATTN_NO_PRECISE_P = 1 << 15, 1 << 16
 
 
 def attn_hint(qw: int = 0, kw: int = 0) -> int:
-    """TF_ATTN_HINT_QW / _KW bits of the fused small-problem kernel: qw in {0 (auto), 1, 2, 4} query waves per
-    workgroup, kw in {0 (auto), 1, 2, 4} key groups."""
-    code = {0: 0, 1: 1, 2: 2, 4: 3}
+    """TF_ATTN_HINT_QW / _KW bits of the fused small-problem kernel: qw in {0 (auto), 1 (the wave-private form), 2, 4}
+    query waves per workgroup, kw in {0 (auto), 1, 2, 4, 8} key groups."""
+    code = {0: 0, 1: 1, 2: 2, 4: 3, 8: 4}
     return (code[qw] << 8) | (code[kw] << 11)
 
 
 ABI_VERSION = 5
-TF_RANK_HEADS, TF_RANK_BANK, TF_RANK_SLOTS, TF_RANK_NO_HALO = 0, 1, 64, 16
+TF_RANK_HEADS, TF_RANK_BANK, TF_RANK_SLOTS, TF_RANK_NO_HALO, TF_RANK_INV_NORM = 0, 1, 64, 16, 32
 TF_ERR_COMM = -6
 
 _c = ctypes
@@ -70,6 +70,7 @@ _SIGNATURES = {
                                      _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     "tf_comm_init_hooks": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p]),
     "tf_comm_init_loopback": (_c.c_int, [_c.c_int, _c.c_int, _c.c_void_p]),
+    "tf_comm_loopback_copies": (_c.c_int, [_c.c_void_p, _c.c_int]),
     # one rank's pivotal pass of a block in one call (csrc/rank_exec.hip; tokenflow_amd/sharded.py NativeShard)
     "tf_rank_create": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p]),
     "tf_rank_destroy": (_c.c_int, [_c.c_void_p]),

@@ -66,7 +66,7 @@ class HipComm:
         self._h, self.rank, self.world = h, rank, world
 
     @classmethod
-    def loopback(cls, rank: int, world: int) -> "HipComm":
+    def loopback(cls, rank: int, world: int, copies: bool = True) -> "HipComm":
         """The wire-less stand-in (tf_comm_init_loopback): every exchange becomes device-to-device copies of the sizes a
         rank of a `world`-GPU run receives, out of this rank's own buffers.  For timing one rank's launch sequence on
         one GPU (tools/rank_step_microbench.py); the received data is meaningless for world > 1."""
@@ -74,6 +74,8 @@ class HipComm:
         h = ctypes.c_void_p()
         _lib.check(_lib.load().tf_comm_init_loopback(rank, world, ctypes.byref(h)), "tf_comm_init_loopback")
         self._h, self.rank, self.world = h, rank, world
+        if not copies:      # the exchanges enqueue nothing at all: the stand-in copies out of the timing too
+            _lib.check(_lib.load().tf_comm_loopback_copies(h, 0), "tf_comm_loopback_copies")
         return self
 
     @classmethod

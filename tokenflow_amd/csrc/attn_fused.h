@@ -24,10 +24,9 @@ struct TfAttnSet {
 
 struct TfFusedPlan {
     int use;    // take the fused kernel
-    int qw;     // query waves per workgroup (32 queries each; they share every staged key tile)
+    int qw;     // query waves per workgroup (32 queries each; they share every staged key tile); 1 = the wave-private form
     int kw;     // key groups per workgroup (the in-workgroup split of the key sequence, merged through LDS)
     int prec;   // P carried as hi + lo bf16 (two P.V MFMAs): removes the rounding of P from the result
-    int vtw;    // development: V transposed while it is written to LDS instead of ds_read_b64_tr_b16
 };
 
 // Shape- and grid-based decision; `flags` = the `inject` bit mask of tf_ext_attn_fwd (hints included).

@@ -70,12 +70,13 @@ struct tf_comm {
     int rank, world;
     int kind = COMM_RCCL;
     tf_comm_hooks hooks = {};
+    bool copies = true;   // loopback only: false = the exchanges move nothing at all (tf_comm_loopback_copies)
 };
 
 namespace {
 
-int copy_async(void* dst, const void* src, size_t bytes, hipStream_t st, const char* what) {
-    if (bytes == 0 || dst == src) return 0;
+int copy_async(void* dst, const void* src, size_t bytes, hipStream_t st, const char* what, bool enabled = true) {
+    if (bytes == 0 || dst == src || !enabled) return 0;
     const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) {
         tf_set_error("%s: hipMemcpyAsync: %s", what, hipGetErrorString(e));
@@ -90,7 +91,7 @@ int loop_allgather_rows(const tf_comm* c, const void* local, void* bank, const i
     const size_t mine = (size_t)rows[c->rank] * rb;
     for (int p = 0; p < c->world; ++p) {
         const size_t n = (size_t)rows[p] * rb;
-        if (const int rc = copy_async(r, local, n < mine ? n : mine, st, "tf_allgather_rows(loopback)")) return rc;
+        if (const int rc = copy_async(r, local, n < mine ? n : mine, st, "tf_allgather_rows(loopback)", c->copies)) return rc;
         r += n;
     }
     return 0;
@@ -100,7 +101,7 @@ int loop_all_to_all(const tf_comm* c, const void* send, void* recv, const int64_
                     size_t rb, hipStream_t st) {
     size_t ns = 0, nr = 0;
     for (int p = 0; p < c->world; ++p) ns += (size_t)send_rows[p] * rb, nr += (size_t)recv_rows[p] * rb;
-    return copy_async(recv, send, ns < nr ? ns : nr, st, "tf_all_to_all_rows(loopback)");
+    return copy_async(recv, send, ns < nr ? ns : nr, st, "tf_all_to_all_rows(loopback)", c->copies);
 }
 
 }  // namespace
@@ -177,6 +178,12 @@ extern "C" int tf_comm_init_loopback(int rank, int world, tf_comm** comm_out) {
     tf_comm* c = new tf_comm{nullptr, rank, world};
     c->kind = COMM_LOOPBACK;
     *comm_out = c;
+    return 0;
+}
+
+extern "C" int tf_comm_loopback_copies(tf_comm* comm, int enabled) {
+    TF_ARG(comm && comm->kind == COMM_LOOPBACK, TF_ERR_COMM, "tf_comm_loopback_copies: not a loopback communicator");
+    comm->copies = enabled != 0;
     return 0;
 }
 
@@ -302,7 +309,7 @@ extern "C" int tf_sendrecv_pivot(tf_comm* comm, const void* const* send, const i
         if (recv_peer >= 0 && send_peer >= 0)
             for (int i = 0; i < n_recv && i < n_send; ++i) {
                 const size_t n = (size_t)(recv_elems[i] < send_elems[i] ? recv_elems[i] : send_elems[i]) * eb;
-                if (const int rc = copy_async(recv[i], send[i], n, st, "tf_sendrecv_pivot(loopback)")) return rc;
+                if (const int rc = copy_async(recv[i], send[i], n, st, "tf_sendrecv_pivot(loopback)", comm->copies)) return rc;
             }
         return 0;
     }

@@ -58,7 +58,6 @@ struct FusedCfg {
     // V row stride (elements).  The transpose read serves 32 lanes per LDS cycle: 4 rows x 64 B; they fall on disjoint
     // bank ranges when the row stride is 64 or 192 (mod 256) bytes.
     static constexpr int VS = DH == 160 ? 160 : 96;
-    static constexpr int VTROW = 40;             // (development form) V^T image [MT*32][32 keys + 8]
     static constexpr int PPR = DH / 8;           // 16-B pieces per K / V row
     static constexpr int K_ELEMS = 32 * KROW;
     static_assert(VS >= MT * 32, "a transpose read must stay inside its V row");
@@ -87,8 +86,6 @@ __device__ __forceinline__ float max_xor32(float x) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-__device__ __forceinline__ int swap23(int x) { return (x & ~12) | ((x & 4) << 1) | ((x & 8) >> 1); }
-
 template <typename E, typename V4>
 __device__ __forceinline__ void store_out4(void* out, int64_t elem_off, f32x4 x, int out_f32) {
     if (out_f32) {
@@ -101,219 +98,111 @@ __device__ __forceinline__ void store_out4(void* out, int64_t elem_off, f32x4 x,
     }
 }
 
-// QW   query waves per workgroup: the workgroup covers 32*QW queries of one (branch, frame, head)
-// KW   key groups: sub-tile j (32 keys) of the problem's key sequence is computed by the waves of group j % KW
-// PREC P as hi + lo (bf16 only)
-// TRV  V row-major in LDS + transpose reads (the product form); false: V^T image built by 2-byte LDS writes
-template <typename T, int DH, int QW, int KW, bool PREC, bool TRV>
-__global__ __launch_bounds__(64 * QW * KW, 1) void ext_attn_fused_kernel(FusedParams p) {
+// Pieces shared by the two kernel forms below -------------------------------------------------------------------------
+
+struct Problem {   // one (set, branch, frame, head, query tile) problem, decoded from blockIdx.x
+    int si, h, qt, f, b, bq, f_lo, n_fr;
+};
+__device__ __forceinline__ Problem decode_problem(const FusedParams& p) {
+    // sets in order (the long bank problems of set 0 first), head fastest (H = 8: one head per XCD)
+    Problem pr;
+    int u = blockIdx.x;
+    pr.si = 0;
+    if (p.n_sets > 1 && u >= p.set[0].n_wg) {
+        u -= p.set[0].n_wg;
+        pr.si = 1;
+    }
+    const FusedSet& st = p.set[pr.si];
+    pr.h = u % st.H;
+    u /= st.H;
+    pr.qt = u % p.nQT;
+    u /= p.nQT;
+    pr.f = u % st.Kq;
+    const int bi = u / st.Kq;
+    // a full set (source + two bank branches) runs its bank branches first
+    pr.b = (st.b0 == 0 && st.nb == 3) ? (bi == 2 ? 0 : bi + 1) : st.b0 + bi;
+    pr.bq = (p.inject && pr.b > 0) ? 0 : pr.b;   // branch whose q and k are used (tokenflow_utils.py:124-130)
+    pr.f_lo = pr.b == 0 ? st.q_frame0 + pr.f : 0;
+    pr.n_fr = pr.b == 0 ? 1 : st.Kb;
+    return pr;
+}
+
+// Wave-uniform cursor over the sub-tiles j0, j0 + step, ... of a problem's key sequence (frames of tpf sub-tiles);
+// past the end it stays on the last sub-tile, so that the branch-free staging loads always have a valid address.
+struct Cursor {
+    int fr, tt, j;
+    __device__ __forceinline__ void init(int j0, int tpf, int nst) {
+        j = j0 < nst ? j0 : nst - 1;
+        fr = 0, tt = j;
+        while (tt >= tpf) tt -= tpf, ++fr;
+    }
+    __device__ __forceinline__ void advance(int step, int tpf, int nst) {
+        if (j + step < nst) {
+            j += step, tt += step;
+            while (tt >= tpf) tt -= tpf, ++fr;
+        }
+    }
+};
+
+// online softmax of one 32-key sub-tile (lane-local; the two lanes of a query share the maximum) and O^T += V^T P
+// with the V^T fragments transpose-read from the row-major V image `vtr` (this lane's address for k-step 0, M-tile 0)
+template <typename T, int DH, bool PREC>
+__device__ __forceinline__ void softmax_pv(f32x16& s, f32x16 (&o)[FusedCfg<DH>::MT], float& m_run, float& l_run, float c,
+                                           const typename T::elem* vtr) {
     typedef FusedCfg<DH> C;
     typedef typename T::elem E;
     typedef typename T::vec8 vec8;
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    mx = max_xor32(mx);
+    if (__any(mx > m_run)) {   // wave-uniform: alpha == 1 exactly for every query otherwise
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);   // exp2(-inf) = 0 on the first sub-tile
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
+    }
+    const float mc = m_run * c;
+    vec8 ph[2], pl[2];   // P of the two 16-key k-steps: registers 0-7 / 8-15 of the accumulator
+    float lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mc));
+        lsum += pr;
+        const E e = (E)pr;
+        ph[r >> 3][r & 7] = e;
+        if constexpr (PREC) pl[r >> 3][r & 7] = (E)(pr - (float)e);
+    }
+    l_run += lsum;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+            const u32x2 a0 = TrRead<T>::rd(vtr + (16 * ks) * C::VS + mt * 32);
+            const u32x2 a1 = TrRead<T>::rd(vtr + (16 * ks + 8) * C::VS + mt * 32);
+            const vec8 a = __builtin_bit_cast(vec8, u32x4{a0[0], a0[1], a1[0], a1[1]});
+            o[mt] = T::mfma32(a, ph[ks], o[mt]);
+            if constexpr (PREC) o[mt] = T::mfma32(a, pl[ks], o[mt]);
+        }
+}
+
+// Epilogue: merge the KW key groups of every query wave through LDS (the staging area is free: the caller has passed a
+// workgroup barrier behind the last read of it) and store.  Group order of the sums is fixed (k = 0 .. KW-1), so the
+// result does not depend on timing; an idle group has m = -inf, l = 0 and weight 0.
+template <typename T, int DH, int QW, int KW>
+__device__ __forceinline__ void merge_store(unsigned char* smem, f32x16 (&o)[FusedCfg<DH>::MT], float m_run, float l_run,
+                                            float c, int wave, int lane, void* out, int64_t out_row, bool q_ok, int out_f32) {
+    typedef FusedCfg<DH> C;
+    typedef typename T::elem E;
     typedef typename T::vec4 vec4;
-    constexpr int NW = QW * KW, NT = 64 * NW;
-    constexpr int SLOT_PIECES = 32 * C::PPR;                    // 16-B pieces of K (and of V) per sub-tile
-    constexpr int NP = (KW * SLOT_PIECES + NT - 1) / NT;        // pieces of K (and of V) per thread and iteration
-    constexpr int V_ELEMS = TRV ? 32 * C::VS : C::MT * 32 * C::VTROW;
-    constexpr int SLOT_ELEMS = C::K_ELEMS + V_ELEMS;
-    constexpr int STAGE_BYTES = KW * SLOT_ELEMS * 2;
-    constexpr int MERGE_BYTES = KW > 1 ? 2 * NW * 16 * 64 * 4 + NW * 64 * 4 : 0;   // two O tile buffers + (m, l) rows
-    constexpr int LDS_BYTES = STAGE_BYTES > MERGE_BYTES ? STAGE_BYTES : MERGE_BYTES;
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    E* lds = reinterpret_cast<E*>(smem);
-    auto sK = [&](int slot) { return lds + slot * SLOT_ELEMS; };
-    auto sV = [&](int slot) { return lds + slot * SLOT_ELEMS + C::K_ELEMS; };
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qw = wave / KW, kw = wave % KW;
+    constexpr int NW = QW * KW;
     const int hi = lane >> 5, l31 = lane & 31;
-    const int S = p.S;
-
-    // ---- problem decode: sets in order (the long bank problems of set 0 first), head fastest (H = 8: one head per XCD)
-    int u = blockIdx.x;
-    int si = 0;
-    if (p.n_sets > 1 && u >= p.set[0].n_wg) {
-        u -= p.set[0].n_wg;
-        si = 1;
-    }
-    const FusedSet& st = p.set[si];
-    const int H = st.H;
-    const int h = u % H;
-    u /= H;
-    const int qt = u % p.nQT;
-    u /= p.nQT;
-    const int f = u % st.Kq;
-    const int bi = u / st.Kq;
-    // a full set (source + two bank branches) runs its bank branches first
-    const int b = (st.b0 == 0 && st.nb == 3) ? (bi == 2 ? 0 : bi + 1) : st.b0 + bi;
-    const int bq = (p.inject && b > 0) ? 0 : b;   // branch whose q and k are used (tokenflow_utils.py:124-130)
-    const int f_lo = b == 0 ? st.q_frame0 + f : 0;
-    const int n_fr = b == 0 ? 1 : st.Kb;
-    const int tpf = p.tpf;
-    const int nst = n_fr * tpf;                   // sub-tiles of this problem
-    const int nit = (nst + KW - 1) / KW;
-
-    const E* kg = reinterpret_cast<const E*>(st.k) + bq * st.k_bs + f_lo * st.k_fs + h * DH;
-    const E* vg = reinterpret_cast<const E*>(st.v) + b * st.v_bs + f_lo * st.v_fs + h * DH;
-    const int64_t k_fs = st.k_fs, v_fs = st.v_fs, ld = st.ld;
-
-    // ---- LDS: zero once (the K pad columns DH..DKP-1 must be zero; everything else is staged before it is read, the
-    //      zero fill only makes the never-stored accumulator rows deterministic)
-    for (int id = tid; id < STAGE_BYTES / 16; id += NT) st16(smem + id * 16, u32x4{0, 0, 0, 0});
-
-    // ---- Q fragments (B operand of S^T = K Q^T), resident for the whole kernel
-    const int q_row = qt * (32 * QW) + qw * 32 + l31;
-    const bool q_ok = q_row < S;
-    vec8 qf[C::KS];
-    {
-        const E* qp = reinterpret_cast<const E*>(st.q) + bq * st.q_bs + f * st.q_fs +
-                      (int64_t)(q_ok ? q_row : S - 1) * st.ld_q + h * DH;
-#pragma unroll
-        for (int t = 0; t < C::KS; ++t) {
-            const int col = 16 * t + 8 * hi;
-            qf[t] = __builtin_bit_cast(vec8, col < DH ? ld16(qp + col) : u32x4{0, 0, 0, 0});
-        }
-    }
-
-    // ---- staging: piece -> (slot, key row, column) is fixed per thread; an iteration only moves the sub-tile index
-    u32x4 rk[NP], rv[NP];
-    int s_slot[NP], s_row[NP], s_col[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int id = min(tid + NT * i, KW * SLOT_PIECES - 1);
-        s_slot[i] = id / SLOT_PIECES;
-        const int rem = id - s_slot[i] * SLOT_PIECES;
-        s_row[i] = rem / C::PPR;
-        s_col[i] = (rem - s_row[i] * C::PPR) * 8;
-    }
-    auto sub_tile = [&](int j, int& fr, int& tt) {   // sub-tile j -> (frame of the problem's sequence, tile in frame)
-        fr = tpf == 1 ? j : (int)__umulhi((unsigned)j, p.tpf_magic);
-        tt = j - fr * tpf;
-    };
-    // branch-free loads: a piece without a sub-tile (past the end of the sequence) or a key row past S re-loads valid
-    // data (clamped indices); such keys are masked / never computed
-    auto stage_load = [&](int it) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int j = min(it * KW + s_slot[i], nst - 1);
-            int fr, tt;
-            sub_tile(j, fr, tt);
-            const int key = min(tt * 32 + s_row[i], S - 1);
-            rk[i] = ld16(kg + fr * k_fs + key * ld + s_col[i]);
-            rv[i] = ld16(vg + fr * v_fs + key * ld + s_col[i]);
-        }
-    };
-    auto stage_write = [&]() {
-#pragma unroll
-        for (int i = 0; i < NP; ++i)
-            if (tid + NT * i < KW * SLOT_PIECES) {
-                st16(sK(s_slot[i]) + s_row[i] * C::KROW + s_col[i], rk[i]);
-                if constexpr (TRV) {
-                    st16(sV(s_slot[i]) + s_row[i] * C::VS + s_col[i], rv[i]);
-                } else {   // V^T image: feature row, key position = S^T accumulator order (swap23)
-                    const vec8 x = __builtin_bit_cast(vec8, rv[i]);
-                    E* dst = sV(s_slot[i]) + s_col[i] * C::VTROW + swap23(s_row[i]);
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) dst[jj * C::VTROW] = x[jj];
-                }
-            }
-    };
-
-    f32x16 o[C::MT];
-    float m_run = -INFINITY;   // running maximum of the raw scores of this wave's sub-tiles
-    float l_run = 0.f;         // this lane's share of the denominator
-#pragma unroll
-    for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[mt][r] = 0.f;
-    const float c = p.c;
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-    // fragment addresses inside this wave's slot
-    const E* kfrag = sK(kw) + l31 * C::KROW + 8 * hi;
-    // transpose read: 16-lane group g = lane >> 4 covers features 16*(g & 1) .. +15 of the M-tile and -- lane half
-    // hi = g >> 1 -- keys 4hi .. 4hi+3 (+8 for the second read) of the 16-key k-step; lane i passes the address of
-    // block[i >> 2][4 * (i & 3)]
-    const int li = lane & 15, lg = lane >> 4;
-    const E* vtr = sV(kw) + (4 * hi + (li >> 2)) * C::VS + 16 * (lg & 1) + 4 * (li & 3);
-    const E* vtw = sV(kw) + l31 * C::VTROW + 8 * hi;   // (development form) V^T image row of this lane
-
-    stage_load(0);
-    __syncthreads();   // zero fill complete before the first staging write
-
-    for (int it = 0; it < nit; ++it) {
-        stage_write();
-        __syncthreads();                        // sub-tiles of this iteration visible
-        if (it + 1 < nit) stage_load(it + 1);   // next iteration's loads fly under the MFMAs
-
-        const int j = it * KW + kw;
-        if (j < nst) {
-            int fr, tt;
-            sub_tile(j, fr, tt);
-            const int key0 = tt * 32;
-            // ---- S^T = K Q^T
-            f32x16 s = zero;
-#pragma unroll
-            for (int t = 0; t < C::KS; ++t) s = T::mfma32(__builtin_bit_cast(vec8, ld16(kfrag + 16 * t)), qf[t], s);
-            if (key0 + 32 > S) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (key0 + cd_row(r, hi) >= S) s[r] = -INFINITY;
-            }
-            // ---- online softmax (lane-local; the two lanes of a query share the maximum)
-            float mx = s[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-            mx = max_xor32(mx);
-            if (__any(mx > m_run)) {
-                const float m_new = fmaxf(m_run, mx);
-                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);   // exp2(-inf) = 0 on the first sub-tile
-                m_run = m_new;
-                l_run *= alpha;
-#pragma unroll
-                for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
-            }
-            const float mc = m_run * c;
-            vec8 ph[2], pl[2];   // P of the two 16-key k-steps: registers 0-7 / 8-15 of the accumulator
-            float lsum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mc));
-                lsum += pr;
-                const E e = (E)pr;
-                ph[r >> 3][r & 7] = e;
-                if constexpr (PREC) pl[r >> 3][r & 7] = (E)(pr - (float)e);
-            }
-            l_run += lsum;
-            // ---- O^T += V^T P
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int mt = 0; mt < C::MT; ++mt) {
-                    vec8 a;
-                    if constexpr (TRV) {
-                        const u32x2 a0 = TrRead<T>::rd(vtr + (16 * ks) * C::VS + mt * 32);
-                        const u32x2 a1 = TrRead<T>::rd(vtr + (16 * ks + 8) * C::VS + mt * 32);
-                        a = __builtin_bit_cast(vec8, u32x4{a0[0], a0[1], a1[0], a1[1]});
-                    } else {
-                        a = __builtin_bit_cast(vec8, ld16(vtw + mt * 32 * C::VTROW + 16 * ks));
-                    }
-                    o[mt] = T::mfma32(a, ph[ks], o[mt]);
-                    if constexpr (PREC) o[mt] = T::mfma32(a, pl[ks], o[mt]);
-                }
-        }
-        __syncthreads();   // every wave is done with this iteration's sub-tiles
-    }
-
-    // ---- epilogue
+    const int qw = wave / KW, kw = wave % KW;
     const float l_wave = l_run + __shfl_xor(l_run, 32);   // both lanes of a query: the wave's denominator
-    const int64_t out_row = b * st.o_bs + f * st.o_fs + (int64_t)q_row * (H * DH) + h * DH;
     auto store_tile = [&](int mt, const f32x16& acc, float inv_l) {
         if (!q_ok) return;
 #pragma unroll
@@ -323,7 +212,7 @@ __global__ __launch_bounds__(64 * QW * KW, 1) void ext_attn_fused_kernel(FusedPa
                 f32x4 w;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) w[i] = acc[rg * 4 + i] * inv_l;
-                store_out4<E, vec4>(st.out, out_row + d0, w, p.out_f32);
+                store_out4<E, vec4>(out, out_row + d0, w, out_f32);
             }
         }
     };
@@ -332,9 +221,7 @@ __global__ __launch_bounds__(64 * QW * KW, 1) void ext_attn_fused_kernel(FusedPa
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt) store_tile(mt, o[mt], inv_l);
     } else {
-        // merge the KW key groups of every query wave through LDS (the staging area is free: last barrier passed).
-        // Group order of the sums is fixed (k = 0 .. KW-1), so the result does not depend on timing.
-        float* stat = reinterpret_cast<float*>(smem + 2 * NW * 16 * 64 * 4);   // [NW][32] m, l interleaved by lane half
+        float* stat = reinterpret_cast<float*>(smem + 2 * NW * 16 * 64 * 4);   // [NW][64]: lanes 0-31 m, lanes 32-63 l
         float* tile = reinterpret_cast<float*>(smem);                         // [2][NW][16][64]
         stat[wave * 64 + lane] = hi == 0 ? m_run : l_wave;
         __syncthreads();
@@ -345,7 +232,7 @@ __global__ __launch_bounds__(64 * QW * KW, 1) void ext_attn_fused_kernel(FusedPa
 #pragma unroll
         for (int k2 = 0; k2 < KW; ++k2) {
             const float mk = stat[(qw * KW + k2) * 64 + l31], lk = stat[(qw * KW + k2) * 64 + 32 + l31];
-            L = fmaf(lk, __builtin_amdgcn_exp2f((mk - M) * c), L);   // an idle group has m = -inf, l = 0: weight 0
+            L = fmaf(lk, __builtin_amdgcn_exp2f((mk - M) * c), L);
         }
         const float w_own = __builtin_amdgcn_exp2f((m_run - M) * c);
         const float inv_l = 1.0f / L;
@@ -370,27 +257,300 @@ __global__ __launch_bounds__(64 * QW * KW, 1) void ext_attn_fused_kernel(FusedPa
     }
 }
 
-template <typename T, int DH, int QW, int KW, bool PREC, bool TRV>
+template <int NW, int KW>
+constexpr int merge_bytes() { return KW > 1 ? 2 * NW * 16 * 64 * 4 + NW * 64 * 4 : 0; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Shared-tile form (QW >= 2 query waves share every staged sub-tile; large grids of small frames).
+// QW   query waves per workgroup: the workgroup covers 32*QW queries of one (branch, frame, head)
+// KW   key groups: sub-tile j (32 keys) of the problem's key sequence is computed by the waves of group j % KW; the QW
+//      waves of group kw stage slot kw together (wave-uniform base pointer + per-thread constant offsets)
+// PREC P as hi + lo (bf16 only)
+template <typename T, int DH, int QW, int KW, bool PREC>
+__global__ __launch_bounds__(64 * QW * KW, 1) void ext_attn_fused_kernel(FusedParams p) {
+    typedef FusedCfg<DH> C;
+    typedef typename T::elem E;
+    typedef typename T::vec8 vec8;
+    constexpr int NW = QW * KW, NT = 64 * NW;
+    constexpr int SLOT_PIECES = 32 * C::PPR;                      // 16-B pieces of K (and of V) per sub-tile
+    constexpr int NP = (SLOT_PIECES + 64 * QW - 1) / (64 * QW);   // pieces of K (and of V) per thread and iteration
+    constexpr int SLOT_ELEMS = C::K_ELEMS + 32 * C::VS;
+    constexpr int STAGE_BYTES = KW * SLOT_ELEMS * 2;
+    static_assert((STAGE_BYTES > merge_bytes<NW, KW>() ? STAGE_BYTES : merge_bytes<NW, KW>()) <= 160 * 1024, "LDS");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    E* lds = reinterpret_cast<E*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qw = wave / KW, kw = wave % KW;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int S = p.S, tpf = p.tpf;
+    E* sK = lds + kw * SLOT_ELEMS;
+    E* sV = sK + C::K_ELEMS;
+
+    const Problem pr = decode_problem(p);
+    const FusedSet& st = p.set[pr.si];
+    const int nst = pr.n_fr * tpf;                // sub-tiles of this problem
+    const int nit = (nst + KW - 1) / KW;
+    const E* kg = reinterpret_cast<const E*>(st.k) + pr.bq * st.k_bs + pr.f_lo * st.k_fs + pr.h * DH;
+    const E* vg = reinterpret_cast<const E*>(st.v) + pr.b * st.v_bs + pr.f_lo * st.v_fs + pr.h * DH;
+    const int64_t k_fs = st.k_fs, v_fs = st.v_fs;
+    const int ld = (int)st.ld;
+
+    // ---- LDS: zero once (the K pad columns DH..DKP-1 must be zero; everything else is staged before it is read)
+    for (int id = tid; id < STAGE_BYTES / 16; id += NT) st16(smem + id * 16, u32x4{0, 0, 0, 0});
+
+    // ---- Q fragments (B operand of S^T = K Q^T), resident for the whole kernel
+    const int q_row = pr.qt * (32 * QW) + qw * 32 + l31;
+    const bool q_ok = q_row < S;
+    vec8 qf[C::KS];
+    {
+        const E* qp = reinterpret_cast<const E*>(st.q) + pr.bq * st.q_bs + pr.f * st.q_fs +
+                      (int64_t)(q_ok ? q_row : S - 1) * st.ld_q + pr.h * DH;
+#pragma unroll
+        for (int t = 0; t < C::KS; ++t) {
+            const int col = 16 * t + 8 * hi;
+            qf[t] = __builtin_bit_cast(vec8, col < DH ? ld16(qp + col) : u32x4{0, 0, 0, 0});
+        }
+    }
+
+    // ---- staging of this wave's slot: piece -> (key row, column) is fixed per thread; an iteration moves a
+    //      wave-uniform base.  Branch-free loads: a key row past S re-loads the last valid row (such keys are masked),
+    //      a slot past the end of the sequence re-loads the last sub-tile (never computed).
+    u32x4 rk[NP], rv[NP];
+    int s_row[NP], s_col[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int id = min(qw * 64 + lane + 64 * QW * i, SLOT_PIECES - 1);
+        s_row[i] = id / C::PPR;
+        s_col[i] = (id - s_row[i] * C::PPR) * 8;
+    }
+    Cursor ldc, cc;   // sub-tile being loaded / computed
+    ldc.init(kw, tpf, nst);
+    cc.init(kw, tpf, nst);
+    auto stage_load = [&]() {
+        const int nvalid = min(32, S - ldc.tt * 32);
+        const E* kb = kg + ldc.fr * k_fs + (int64_t)(ldc.tt * 32) * ld;
+        const E* vb = vg + ldc.fr * v_fs + (int64_t)(ldc.tt * 32) * ld;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int off = min(s_row[i], nvalid - 1) * ld + s_col[i];
+            rk[i] = ld16(kb + off);
+            rv[i] = ld16(vb + off);
+        }
+        ldc.advance(KW, tpf, nst);
+    };
+    auto stage_write = [&]() {
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            if (qw * 64 + lane + 64 * QW * i < SLOT_PIECES) {
+                st16(sK + s_row[i] * C::KROW + s_col[i], rk[i]);
+                st16(sV + s_row[i] * C::VS + s_col[i], rv[i]);
+            }
+    };
+
+    f32x16 o[C::MT];
+    float m_run = -INFINITY;   // running maximum of the raw scores of this wave's sub-tiles
+    float l_run = 0.f;         // this lane's share of the denominator
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[mt][r] = 0.f;
+    const float c = p.c;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // fragment addresses inside this wave's slot
+    const E* kfrag = sK + l31 * C::KROW + 8 * hi;
+    // transpose read: 16-lane group g = lane >> 4 covers features 16*(g & 1) .. +15 of the M-tile and -- lane half
+    // hi = g >> 1 -- keys 4hi .. 4hi+3 (+8 for the second read) of the 16-key k-step; lane i passes the address of
+    // block[i >> 2][4 * (i & 3)]
+    const int li = lane & 15, lg = lane >> 4;
+    const E* vtr = sV + (4 * hi + (li >> 2)) * C::VS + 16 * (lg & 1) + 4 * (li & 3);
+
+    stage_load();
+    __syncthreads();   // zero fill complete before the first staging write
+
+    for (int it = 0; it < nit; ++it) {
+        stage_write();
+        __syncthreads();   // sub-tiles of this iteration visible
+        stage_load();      // next iteration's loads fly under the MFMAs (past the end: a harmless re-load)
+        if (it * KW + kw < nst) {
+            const int key0 = cc.tt * 32;
+            f32x16 s = zero;   // S^T = K Q^T
+#pragma unroll
+            for (int t = 0; t < C::KS; ++t) s = T::mfma32(__builtin_bit_cast(vec8, ld16(kfrag + 16 * t)), qf[t], s);
+            if (key0 + 32 > S) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key0 + cd_row(r, hi) >= S) s[r] = -INFINITY;
+            }
+            softmax_pv<T, DH, PREC>(s, o, m_run, l_run, c, vtr);
+            cc.advance(KW, tpf, nst);
+        }
+        __syncthreads();   // every wave is done with this iteration's sub-tiles
+    }
+    const int64_t out_row = pr.b * st.o_bs + pr.f * st.o_fs + (int64_t)q_row * (st.H * DH) + pr.h * DH;
+    merge_store<T, DH, QW, KW>(smem, o, m_run, l_run, c, wave, lane, st.out, out_row, q_ok, p.out_f32);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-private form (small grids: a sharded rank's share of a level, BASELINE config 1): ONE 32-query tile per workgroup,
+// its key sequence split over KW = 4 or 8 waves, and NOTHING shared between the waves until the merge -- so the main
+// loop has no workgroup barrier at all: every wave streams its own sub-tiles at its own pace.
+//   * K: the MFMA A fragments (a key row per lane, 16 B per k-step) are loaded straight from global memory into
+//     registers, one sub-tile ahead (these problems are L2-resident; LDS would buy coalescing only);
+//   * V: loaded one sub-tile ahead (lane = half a key row), written row-major into the wave's private LDS region and
+//     transpose-read as V^T fragments.  LDS operations of one wave execute in order, so write -> read -> next write
+//     need no barrier;
+//   * Q: registers; at Dh = 160 (where the accumulators alone are 80 registers) in LDS, shared by the KW waves.
+// Same arithmetic per (query, head) as the shared-tile form with the same KW: bit-identical results.
+template <typename T, int DH, int KW, bool PREC>
+__global__ __launch_bounds__(64 * KW, 1) void ext_attn_fused_wp_kernel(FusedParams p) {
+    typedef FusedCfg<DH> C;
+    typedef typename T::elem E;
+    typedef typename T::vec8 vec8;
+    constexpr int NT = 64 * KW;
+    constexpr bool LQ = DH == 160;                    // Q fragments from LDS
+    constexpr int NPH = (C::PPR + 1) / 2;             // 16-B pieces of V per lane and sub-tile (half a row)
+    constexpr int V_ELEMS = 32 * C::VS;
+    constexpr int STAGE_BYTES = (KW * V_ELEMS + (LQ ? C::K_ELEMS : 0)) * 2;
+    static_assert((STAGE_BYTES > merge_bytes<KW, KW>() ? STAGE_BYTES : merge_bytes<KW, KW>()) <= 160 * 1024, "LDS");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    E* lds = reinterpret_cast<E*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int kw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int S = p.S, tpf = p.tpf;
+    E* sV = lds + kw * V_ELEMS;
+    E* sQ = lds + KW * V_ELEMS;
+
+    const Problem pr = decode_problem(p);
+    const FusedSet& st = p.set[pr.si];
+    const int nst = pr.n_fr * tpf;
+    const int nmine = kw < nst ? (nst - kw + KW - 1) / KW : 0;   // sub-tiles of this wave: kw, kw + KW, ...
+    const E* kg = reinterpret_cast<const E*>(st.k) + pr.bq * st.k_bs + pr.f_lo * st.k_fs + pr.h * DH;
+    const E* vg = reinterpret_cast<const E*>(st.v) + pr.b * st.v_bs + pr.f_lo * st.v_fs + pr.h * DH;
+    const int64_t k_fs = st.k_fs, v_fs = st.v_fs;
+    const int ld = (int)st.ld;
+
+    // ---- Q fragments
+    const int q_row = pr.qt * 32 + l31;
+    const bool q_ok = q_row < S;
+    const E* qp = reinterpret_cast<const E*>(st.q) + pr.bq * st.q_bs + pr.f * st.q_fs +
+                  (int64_t)(q_ok ? q_row : S - 1) * st.ld_q + pr.h * DH;
+    vec8 qf[LQ ? 1 : C::KS];
+    if constexpr (LQ) {
+        // the 32 x DH query tile, row-major with the K image's row stride: every wave copies 32 / KW rows
+        for (int id = tid; id < 32 * C::PPR; id += NT) {
+            const int row = id / C::PPR, pc = id - row * C::PPR;
+            const int qr = min(pr.qt * 32 + row, S - 1);
+            st16(sQ + row * C::KROW + pc * 8,
+                 ld16(reinterpret_cast<const E*>(st.q) + pr.bq * st.q_bs + pr.f * st.q_fs + (int64_t)qr * st.ld_q + pr.h * DH + pc * 8));
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int t = 0; t < C::KS; ++t) {
+            const int col = 16 * t + 8 * hi;
+            qf[t] = __builtin_bit_cast(vec8, col < DH ? ld16(qp + col) : u32x4{0, 0, 0, 0});
+        }
+    }
+    const E* qfrag = sQ + l31 * C::KROW + 8 * hi;
+
+    // ---- loads of one sub-tile, one ahead of its use; branch-free (clamped rows / cursor), see the shared-tile form
+    u32x4 rk[C::KS], rv[NPH];
+    const int v_row = lane >> 1, v_pc0 = (lane & 1) * NPH;
+    Cursor ldc;
+    ldc.init(kw, tpf, nst);
+    int key0_next = 0;
+    auto load_tile = [&]() {
+        const int nvalid = min(32, S - ldc.tt * 32);
+        key0_next = ldc.tt * 32;
+        const E* kb = kg + ldc.fr * k_fs + (int64_t)(ldc.tt * 32) * ld + min(l31, nvalid - 1) * ld + 8 * hi;
+        const E* vb = vg + ldc.fr * v_fs + (int64_t)(ldc.tt * 32) * ld + min(v_row, nvalid - 1) * ld;
+#pragma unroll
+        for (int t = 0; t < C::KS; ++t) rk[t] = (16 * t + 8 * hi < DH) ? ld16(kb + 16 * t) : u32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < NPH; ++i) rv[i] = ld16(vb + min(v_pc0 + i, C::PPR - 1) * 8);
+        ldc.advance(KW, tpf, nst);
+    };
+
+    f32x16 o[C::MT];
+    float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[mt][r] = 0.f;
+    const float c = p.c;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int li = lane & 15, lg = lane >> 4;
+    const E* vtr = sV + (4 * hi + (li >> 2)) * C::VS + 16 * (lg & 1) + 4 * (li & 3);
+
+    load_tile();
+    for (int i = 0; i < nmine; ++i) {
+        const int key0 = key0_next;
+        // V(i) -> this wave's LDS region (the transpose reads of sub-tile i-1 precede these writes in the wave's
+        // in-order LDS stream)
+#pragma unroll
+        for (int j2 = 0; j2 < NPH; ++j2)
+            if (v_pc0 + j2 < C::PPR) st16(sV + v_row * C::VS + (v_pc0 + j2) * 8, rv[j2]);
+        __builtin_amdgcn_wave_barrier();
+        // S^T = K Q^T from the register-resident K fragments
+        f32x16 s = zero;
+#pragma unroll
+        for (int t = 0; t < C::KS; ++t) {
+            const vec8 qv = LQ ? __builtin_bit_cast(vec8, ld16(qfrag + 16 * t)) : qf[LQ ? 0 : t];
+            s = T::mfma32(__builtin_bit_cast(vec8, rk[t]), qv, s);
+        }
+        load_tile();   // K(i+1), V(i+1) fly under the softmax and the P.V MFMAs (past the end: a harmless re-load)
+        if (key0 + 32 > S) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (key0 + cd_row(r, hi) >= S) s[r] = -INFINITY;
+        }
+        softmax_pv<T, DH, PREC>(s, o, m_run, l_run, c, vtr);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();   // every wave has left its loop: the staging area becomes the merge area
+    const int64_t out_row = pr.b * st.o_bs + pr.f * st.o_fs + (int64_t)q_row * (st.H * DH) + pr.h * DH;
+    merge_store<T, DH, 1, KW>(smem, o, m_run, l_run, c, kw, lane, st.out, out_row, q_ok, p.out_f32);
+}
+
+template <typename T, int DH, int QW, int KW, bool PREC>
 int launch_fused(const FusedParams& p, unsigned grid, hipStream_t st) {
     typedef FusedCfg<DH> C;
     constexpr int NW = QW * KW;
-    constexpr int V_ELEMS = TRV ? 32 * C::VS : C::MT * 32 * C::VTROW;
-    constexpr int STAGE_BYTES = KW * (C::K_ELEMS + V_ELEMS) * 2;
-    constexpr int MERGE_BYTES = KW > 1 ? 2 * NW * 16 * 64 * 4 + NW * 64 * 4 : 0;
-    constexpr int lds = STAGE_BYTES > MERGE_BYTES ? STAGE_BYTES : MERGE_BYTES;
-    auto kern = ext_attn_fused_kernel<T, DH, QW, KW, PREC, TRV>;
+    constexpr int STAGE_BYTES = KW * (C::K_ELEMS + 32 * C::VS) * 2;
+    constexpr int lds = STAGE_BYTES > merge_bytes<NW, KW>() ? STAGE_BYTES : merge_bytes<NW, KW>();
+    auto kern = ext_attn_fused_kernel<T, DH, QW, KW, PREC>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, st, p);
     TF_LAUNCH_CHECK("tf_ext_attn_fwd(fused)");
     return 0;
 }
 
-template <typename T, int DH, bool PREC, bool TRV>
+template <typename T, int DH, int KW, bool PREC>
+int launch_fused_wp(const FusedParams& p, unsigned grid, hipStream_t st) {
+    typedef FusedCfg<DH> C;
+    constexpr int STAGE_BYTES = (KW * 32 * C::VS + (DH == 160 ? C::K_ELEMS : 0)) * 2;
+    constexpr int lds = STAGE_BYTES > merge_bytes<KW, KW>() ? STAGE_BYTES : merge_bytes<KW, KW>();
+    auto kern = ext_attn_fused_wp_kernel<T, DH, KW, PREC>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * KW), lds, st, p);
+    TF_LAUNCH_CHECK("tf_ext_attn_fwd(fused)");
+    return 0;
+}
+
+template <typename T, int DH, bool PREC>
 int dispatch_geom(const FusedParams& p, unsigned grid, int qw, int kw, hipStream_t st) {
-    if (qw == 1 && kw == 4) return launch_fused<T, DH, 1, 4, PREC, TRV>(p, grid, st);
-    if (qw == 2 && kw == 4) return launch_fused<T, DH, 2, 4, PREC, TRV>(p, grid, st);
-    if (qw == 4 && kw == 2) return launch_fused<T, DH, 4, 2, PREC, TRV>(p, grid, st);
-    if (qw == 4 && kw == 1) return launch_fused<T, DH, 4, 1, PREC, TRV>(p, grid, st);
+    if (qw == 1 && kw == 4) return launch_fused_wp<T, DH, 4, PREC>(p, grid, st);
+    if (qw == 1 && kw == 8) return launch_fused_wp<T, DH, 8, PREC>(p, grid, st);
+    if (qw == 2 && kw == 4) return launch_fused<T, DH, 2, 4, PREC>(p, grid, st);
+    if (qw == 4 && kw == 2) return launch_fused<T, DH, 4, 2, PREC>(p, grid, st);
+    if (qw == 4 && kw == 1) return launch_fused<T, DH, 4, 1, PREC>(p, grid, st);
     tf_set_error("tf_ext_attn_fwd(fused): geometry (%d query waves, %d key groups) is not built", qw, kw);
     return TF_ERR_SHAPE;
 }
@@ -398,17 +558,8 @@ int dispatch_geom(const FusedParams& p, unsigned grid, int qw, int kw, hipStream
 template <typename T, int DH>
 int dispatch_prec(const FusedParams& p, unsigned grid, const TfFusedPlan& plan, hipStream_t st) {
     constexpr bool bf = std::is_same<T, BF16>::value;
-    if (plan.vtw) {
-#ifdef TF_FUSED_WITH_VT_WRITE
-        if (bf && plan.prec) return dispatch_geom<T, DH, bf, false>(p, grid, plan.qw, plan.kw, st);
-        return dispatch_geom<T, DH, false, false>(p, grid, plan.qw, plan.kw, st);
-#else
-        tf_set_error("tf_ext_attn_fwd(fused): the transposing-write form is a development build option");
-        return TF_ERR_SHAPE;
-#endif
-    }
-    if (bf && plan.prec) return dispatch_geom<T, DH, bf, true>(p, grid, plan.qw, plan.kw, st);
-    return dispatch_geom<T, DH, false, true>(p, grid, plan.qw, plan.kw, st);
+    if (bf && plan.prec) return dispatch_geom<T, DH, bf>(p, grid, plan.qw, plan.kw, st);
+    return dispatch_geom<T, DH, false>(p, grid, plan.qw, plan.kw, st);
 }
 
 template <typename T>
@@ -430,40 +581,54 @@ int64_t n_problems(const TfAttnSet* sets, int n_sets) {
 
 }  // namespace
 
-// Which calls take the fused kernel, and in which geometry.
-//   * KW (the in-workgroup key split) and PREC change the arithmetic of a (query, head); QW and the grid do not.
-//   * shape rule (any mode): S <= 256 -> KW = 4.  A function of (S, Dh, bank frames) only, so a sharded rank and the
-//     single GPU agree and TF_ATTN_NO_SPLIT results stay bit-identical across grid sizes.
-//   * grid rule (only without TF_ATTN_NO_SPLIT): S <= 1024 and a grid of at most FUSED_MAX_QWAVES 32-query waves (a
-//     sharded rank's level 1, BASELINE config 1 level 0) -> KW = 4.
+// Which calls take the fused kernel, and in which geometry (measured: profiles/r04_fused_microbench.txt).
+//   * KW (the in-workgroup key split) and PREC change the arithmetic of a (query, head); QW, the staging form
+//     (wave-private / shared tiles) and the grid do not.
+//   * TF_ATTN_NO_SPLIT (bit-stable mode): S <= 256 -> KW = 4, whatever the grid, the bank size or the branches of the
+//     call -- a function of (S, Dh, dtype) only, so a sharded rank's calls and the single-GPU call agree and one-pass
+//     results stay bit-identical across grid sizes.  Larger frames keep the streaming kernels' one-pass form.
+//   * otherwise (free to choose per grid): S <= 256 -> small grids (<= 1024 32-query tiles: a sharded rank, BASELINE
+//     config 1, the 8x8 level) take the wave-private form with KW = 4; larger grids the shared-tile form without a
+//     key split (4 query waves share every sub-tile), unless the bank is long (> 4096 keys: the hi + lo P.V costs
+//     more there than the pre-pass it saves, and the rounding of P averages out).  256 < S <= 1024 -> only small
+//     grids (a sharded rank's level 1): wave-private, KW = 4.
 //   * PREC: bf16 and S <= 256 (shape only, and independent of which branches a call computes: the parts of a
 //     sharded rank's pass must round exactly as the single-GPU call does).
-//   * QW: 2 query waves per workgroup (a staged sub-tile is shared by two waves) while that leaves >= 256 workgroups.
-#ifndef TF_TUNE_FUSED_MAX_QWAVES
-#define TF_TUNE_FUSED_MAX_QWAVES 3072
+#ifndef TF_TUNE_FUSED_SMALL_GRID
+#define TF_TUNE_FUSED_SMALL_GRID 1024
 #endif
 TfFusedPlan tf_attn_fused_plan(const TfAttnSet* sets, int n_sets, int S, int Dh, int dtype, int flags) {
     TfFusedPlan pl{};
     if (flags & TF_ATTN_NO_FUSED) return pl;
     if (!(Dh == 40 || Dh == 64 || Dh == 80 || Dh == 160) || (dtype != TF_BF16 && dtype != TF_F16)) return pl;
     if (flags & TF_ATTN_FOLD_SCALE) return pl;   // the folded-scale opt-in is a Dh = 40 streaming-kernel form
-    const int64_t n_prob = n_problems(sets, n_sets);
-    const int64_t qwaves = n_prob * ((S + 31) / 32);
-    const bool forced = (flags & TF_ATTN_FUSED) != 0;
-    const bool shape_rule = S <= 256;
-    const bool grid_rule = !(flags & TF_ATTN_NO_SPLIT) && S <= 1024 && qwaves <= TF_TUNE_FUSED_MAX_QWAVES;
-    if (!forced && !shape_rule && !grid_rule) return pl;
-    pl.use = 1;
-    pl.kw = 4;
-    pl.qw = n_prob * ((S + 63) / 64) >= 256 ? 2 : 1;
+    const int64_t n_qt = n_problems(sets, n_sets) * ((S + 31) / 32);   // 32-query tiles of the launch
+    int Kb = 1;
+    for (int i = 0; i < n_sets; ++i)
+        if (sets[i].b0 + sets[i].nb > 1 && sets[i].Kb > Kb) Kb = sets[i].Kb;
+    const bool small_grid = n_qt <= TF_TUNE_FUSED_SMALL_GRID;
+    if (flags & TF_ATTN_NO_SPLIT) {
+        pl.use = S <= 256;
+        pl.kw = 4;
+        pl.qw = small_grid ? 1 : 2;
+    } else if (S <= 256) {
+        pl.use = small_grid || (int64_t)Kb * S <= 4096;
+        pl.kw = small_grid ? 4 : 1;
+        pl.qw = small_grid ? 1 : 4;
+    } else {
+        pl.use = S <= 1024 && small_grid;
+        pl.kw = 4;
+        pl.qw = 1;
+    }
+    if (flags & TF_ATTN_FUSED) pl.use = 1;
+    if (!pl.use) return pl;
     pl.prec = dtype == TF_BF16 && S <= 256;
     // hints (development / A-B measurements; 0 = automatic)
     const int hq = (flags >> 8) & 7, hk = (flags >> 11) & 7;
     if (hq) pl.qw = 1 << (hq - 1);
-    if (hk) pl.kw = 1 << (hk - 1);
+    if (hk) pl.kw = 1 << (hk - 1);   // codes 1..4 = 1, 2, 4, 8 key groups
     if (flags & TF_ATTN_PRECISE_P) pl.prec = dtype == TF_BF16;
     if (flags & TF_ATTN_NO_PRECISE_P) pl.prec = 0;
-    pl.vtw = (flags & TF_ATTN_HINT_VT_WRITE) ? 1 : 0;
     return pl;
 }
 

@@ -33,6 +33,39 @@ __global__ __launch_bounds__(256) void head_pack_kernel(SlabPtrs sl, unsigned ch
     }
 }
 
+// The same launch with extra workgroups behind the packing ones that compute inv_norm[r] = 1 / ||piv[r]|| of the rank's
+// pivot rows (tf_pivot_inv_norm's arithmetic, one wave per row): at the coarse levels of a sharded rank a launch costs
+// more than either piece of work.
+template <typename T>
+__global__ __launch_bounds__(256) void head_pack_norm_kernel(SlabPtrs sl, unsigned char* __restrict__ send, int ns, int W,
+                                                             int Kl, int S, int hd_pieces, int64_t ld_bytes, int nb_pack,
+                                                             const typename T::elem* __restrict__ piv,
+                                                             float* __restrict__ inv_norm, int64_t rows, int D) {
+    if ((int)blockIdx.x < nb_pack) {
+        const int64_t total = (int64_t)W * Kl * ns * S * hd_pieces;
+        for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)nb_pack * 256) {
+            int64_t t = g;
+            const int pc = (int)(t % hd_pieces);
+            t /= hd_pieces;
+            const int s = (int)(t % S);
+            t /= S;
+            const int i = (int)(t % ns);
+            t /= ns;
+            const int f = (int)(t % Kl);
+            const int w = (int)(t / Kl);
+            const unsigned char* src = sl.src[i] + f * sl.fs[i] + (int64_t)s * ld_bytes + ((int64_t)w * hd_pieces + pc) * 16;
+            st16(send + g * 16, ld16(src));
+        }
+    } else {
+        const int lane = threadIdx.x & 63;
+        const int64_t nwaves = (int64_t)(gridDim.x - nb_pack) * 4;
+        for (int64_t r = (int64_t)(blockIdx.x - nb_pack) * 4 + (threadIdx.x >> 6); r < rows; r += nwaves) {
+            const float inv = tf_row_inv_norm<T>(piv + r * D, D, lane);
+            if (lane == 0) inv_norm[r] = inv;
+        }
+    }
+}
+
 // dst_b[f][s][w*hd ...] = recv[w][f][b][s][hd]
 __global__ __launch_bounds__(256) void head_unpack_kernel(const unsigned char* __restrict__ recv, SlabPtrs sl, int nb,
                                                           int W, int Kl, int S, int hd_pieces, int64_t ld_bytes) {
@@ -69,6 +102,37 @@ int check(const char* name, const void* const* slabs, const int64_t* fs, int n, 
 }
 
 }  // namespace
+
+int tf_head_pack_norm(const void* const* slabs, const int64_t* frame_strides, int ns, void* send, int W, int Kl, int S,
+                      int hd, int64_t ld, int elem_bytes, const void* piv, float* inv_norm, int64_t rows, int D, int dtype,
+                      void* stream) {
+    if (!piv) return tf_head_pack(slabs, frame_strides, ns, send, W, Kl, S, hd, ld, elem_bytes, stream);
+    if (const int rc = check("tf_head_pack", slabs, frame_strides, ns, send, W, Kl, S, hd, ld, elem_bytes)) return rc;
+    TF_ARG(inv_norm && rows > 0 && D > 0 && D % 8 == 0 && (dtype == TF_BF16 || dtype == TF_F16) && tf_aligned16(piv),
+           TF_ERR_SHAPE, "tf_head_pack(+inverse norms): rows=%lld D=%d dtype=%d", (long long)rows, D, dtype);
+    SlabPtrs sl{};
+    for (int i = 0; i < ns; ++i) {
+        sl.src[i] = static_cast<const unsigned char*>(slabs[i]);
+        sl.fs[i] = frame_strides[i] * elem_bytes;
+    }
+    const int hd_pieces = hd * elem_bytes / 16;
+    const int64_t total = (int64_t)W * Kl * ns * S * hd_pieces;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    int64_t nblocks = (rows + 3) / 4;
+    if (nblocks > 4096) nblocks = 4096;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == TF_BF16)
+        hipLaunchKernelGGL(head_pack_norm_kernel<BF16>, dim3((unsigned)(blocks + nblocks)), dim3(256), 0, st, sl,
+                           static_cast<unsigned char*>(send), ns, W, Kl, S, hd_pieces, ld * elem_bytes, (int)blocks,
+                           static_cast<const __bf16*>(piv), inv_norm, rows, D);
+    else
+        hipLaunchKernelGGL(head_pack_norm_kernel<F16>, dim3((unsigned)(blocks + nblocks)), dim3(256), 0, st, sl,
+                           static_cast<unsigned char*>(send), ns, W, Kl, S, hd_pieces, ld * elem_bytes, (int)blocks,
+                           static_cast<const _Float16*>(piv), inv_norm, rows, D);
+    TF_LAUNCH_CHECK("tf_head_pack");
+    return 0;
+}
 
 extern "C" int tf_head_pack(const void* const* slabs, const int64_t* frame_strides, int ns, void* send, int W, int Kl,
                             int S, int hd, int64_t ld, int elem_bytes, void* stream) {

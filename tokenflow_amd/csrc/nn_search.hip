@@ -48,22 +48,9 @@ __global__ __launch_bounds__(256) void pivot_inv_norm_kernel(const typename T::e
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
-    const int pieces = D >> 3;
     for (int64_t r = wave; r < rows; r += nwaves) {
-        const typename T::elem* row = piv + r * D;
-        float s = 0.f;
-        for (int p = lane; p < pieces; p += 64) {
-            u32x4 raw = ld16(row + p * 8);
-            typename T::vec8 v = __builtin_bit_cast(typename T::vec8, raw);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float x = (float)v[i];
-                s = fmaf(x, x, s);
-            }
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) inv_norm[r] = 1.0f / sqrtf(s);
+        const float inv = tf_row_inv_norm<T>(piv + r * D, D, lane);
+        if (lane == 0) inv_norm[r] = inv;
     }
 }
 

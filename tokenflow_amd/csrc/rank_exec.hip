@@ -172,12 +172,14 @@ extern "C" int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const 
                                void* piv_ext, float* inv_ext, void* kfo_ext, int S, int H, int Dh, float scale,
                                int flags, int dtype, int mode, int slot, void* ws, size_t ws_bytes, void* stream) {
     const bool no_halo = (mode & TF_RANK_NO_HALO) != 0;   // attention only: kfo_ext is a plain [3, Kl, S, H*Dh] output
-    mode &= ~TF_RANK_NO_HALO;
+    const bool want_inv = (mode & TF_RANK_INV_NORM) != 0; // the call computes the local pivots' inverse norms (in its pack launch)
+    mode &= ~(TF_RANK_NO_HALO | TF_RANK_INV_NORM);
     TF_ARG(rk && q && k && v && st_in && kfo_ext && ws && (no_halo || (piv_ext && inv_ext)), TF_ERR_NULL,
            "tf_rank_pivotal: null pointer");
     TF_ARG(dtype == TF_BF16 || dtype == TF_F16, TF_ERR_DTYPE, "tf_rank_pivotal: dtype %d (bf16/f16 only)", dtype);
     TF_ARG(mode == TF_RANK_HEADS || mode == TF_RANK_BANK, TF_ERR_SHAPE, "tf_rank_pivotal: mode %d", mode);
     TF_ARG(slot >= 0 && slot < TF_RANK_SLOTS, TF_ERR_SHAPE, "tf_rank_pivotal: slot %d outside [0, %d)", slot, TF_RANK_SLOTS);
+    TF_ARG(!(want_inv && no_halo), TF_ERR_SHAPE, "tf_rank_pivotal: TF_RANK_INV_NORM needs the propagation state (no TF_RANK_NO_HALO)");
     TF_ARG(!(flags & (TF_ATTN_BANK_ONLY | TF_ATTN_SOURCE_ONLY)), TF_ERR_SHAPE,
            "tf_rank_pivotal: the part flags are the executor's own");
     TF_ARG(ws_bytes >= tf_rank_pivotal_workspace_bytes(rk, S, H, Dh, dtype), TF_ERR_WORKSPACE,
@@ -199,7 +201,12 @@ extern "C" int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const 
     const int inject = flags & TF_ATTN_INJECT;
     if (!no_halo) rk->halo_set[slot] = false;
 
+    // the local keyframes' pivots and inverse norms (slots o.. of the halo-extended state)
+    const E* piv_loc = want_inv ? piv + (int64_t)o * SD : nullptr;
+    float* inv_loc = want_inv ? inv_ext + (int64_t)o * S : nullptr;
     if (W == 1) {
+        if (want_inv)
+            if (const int rc = tf_pivot_inv_norm(piv_loc, inv_loc, (int64_t)Kl * S, (int)D, dtype, stream)) return rc;
         const int64_t strides[9] = {q_bs, q_fs, k_bs, k_fs, v_bs, v_fs, o_bs, SD, ld_q};
         return tf_ext_attn_fwd_strided(q, k, v, out_loc, K, K, 0, S, H, Dh, ld, strides, scale, flags, dtype, ws, ws_bytes,
                                        stream);
@@ -231,7 +238,9 @@ extern "C" int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const 
             slabs[4] = ve + v_bs, slabs[5] = ve + 2 * v_bs;
             fss[0] = fss[1] = q_fs, fss[2] = fss[3] = k_fs, fss[4] = fss[5] = v_fs;
         }
-        if (const int rc = tf_head_pack(slabs, fss, ns, send, W, Kl, S, (int)hd, ld, 2, stream)) return rc;
+        if (const int rc = tf_head_pack_norm(slabs, fss, ns, send, W, Kl, S, (int)hd, ld, 2, piv_loc, inv_loc,
+                                             (int64_t)Kl * S, (int)D, dtype, stream))
+            return rc;
         // ---- the two tensor sets of the attention: the bank branches on this rank's head group over all K frames, read
         //      from `recv` and written to `send2` in place (both laid out for the collectives), and the source branch of
         //      the local frames on the local projections.
@@ -260,32 +269,35 @@ extern "C" int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const 
         // small problems (the coarse levels, a rank's share of the middle ones): ONE launch for both sets behind the
         // exchange -- no V^T pre-passes, no split + merge pair, no separate source launch (csrc/ext_attn_fused.hip)
         const TfFusedPlan plan = tf_attn_fused_plan(sets, 2, S, Dh, dtype, flags);
-        // ---- first all-to-all (exchange stream) and, under it, the source branch of the local frames
-        if (const int rc = order(rk, st, rk->xs, "tf_rank_pivotal")) return rc;
-        if (const int rc = tf_all_to_all_rows(rk->comm, send, recv, own, cnt, ns * Shd, dtype, rk->xs)) return rc;
-        hipEvent_t arrived = rk->next();
-        TF_HIP(hipEventRecord(arrived, rk->xs), "tf_rank_pivotal");
-        if (!plan.use) {
-            const int64_t strides[9] = {q_bs, q_fs, k_bs, k_fs, v_bs, v_fs, o_bs, SD, ld_q};
-            if (const int rc = tf_ext_attn_fwd_strided(q, k, v, out_loc, Kl, Kl, 0, S, H, Dh, ld, strides, scale,
-                                                       flags | TF_ATTN_SOURCE_ONLY, dtype, wsb + L.ws_src, L.ws_src_bytes,
-                                                       stream))
-                return rc;
-        }
-        TF_HIP(hipStreamWaitEvent(st, arrived, 0), "tf_rank_pivotal");
         if (plan.use) {
+            // Everything on the caller's stream: there is nothing to run beside the first exchange any more, and a
+            // hand-over between two streams costs ~10 us of idle device each way (profiles/r04_rank_timeline_v1.txt:
+            // four of them per block were 45 us of a 120 us block at the coarse levels).
+            if (const int rc = tf_all_to_all_rows(rk->comm, send, recv, own, cnt, ns * Shd, dtype, st)) return rc;
             if (const int rc = tf_attn_fused_launch(sets, 2, S, Dh, scale, flags, dtype, plan, st)) return rc;
         } else {
+            // ---- first all-to-all on the exchange stream and, under it, the source branch of the local frames
+            if (const int rc = order(rk, st, rk->xs, "tf_rank_pivotal")) return rc;
+            if (const int rc = tf_all_to_all_rows(rk->comm, send, recv, own, cnt, ns * Shd, dtype, rk->xs)) return rc;
+            hipEvent_t arrived = rk->next();
+            TF_HIP(hipEventRecord(arrived, rk->xs), "tf_rank_pivotal");
+            {
+                const int64_t strides[9] = {q_bs, q_fs, k_bs, k_fs, v_bs, v_fs, o_bs, SD, ld_q};
+                if (const int rc = tf_ext_attn_fwd_strided(q, k, v, out_loc, Kl, Kl, 0, S, H, Dh, ld, strides, scale,
+                                                           flags | TF_ATTN_SOURCE_ONLY, dtype, wsb + L.ws_src,
+                                                           L.ws_src_bytes, stream))
+                    return rc;
+            }
+            TF_HIP(hipStreamWaitEvent(st, arrived, 0), "tf_rank_pivotal");
             const int64_t strides[9] = {Shd, fs_r, Shd, fs_r, Shd, fs_r, Shd, 2 * Shd, hd};
             if (const int rc = tf_ext_attn_fwd_strided(qb, kb, vb, ob, K, K, 0, S, Hl, Dh, hd, strides, scale,
                                                        flags | TF_ATTN_BANK_ONLY, dtype, wsb + L.ws_bank, L.ws_bank_bytes,
                                                        stream))
                 return rc;
         }
-        // ---- outputs back to the frame owners
-        if (const int rc = order(rk, st, rk->xs, "tf_rank_pivotal")) return rc;
-        if (const int rc = tf_all_to_all_rows(rk->comm, send2, recv2, cnt, own, 2 * Shd, dtype, rk->xs)) return rc;
-        if (const int rc = order(rk, rk->xs, st, "tf_rank_pivotal")) return rc;
+        // ---- outputs back to the frame owners: on the caller's stream (nothing can run beside this exchange: the
+        //      unpack and the next block need its result)
+        if (const int rc = tf_all_to_all_rows(rk->comm, send2, recv2, cnt, own, 2 * Shd, dtype, st)) return rc;
         void* dsts[2] = {out_loc + o_bs, out_loc + 2 * o_bs};
         const int64_t dfs[2] = {SD, SD};
         if (const int rc = tf_head_unpack(recv2, dsts, dfs, 2, W, Kl, S, (int)hd, D, 2, stream)) return rc;
@@ -307,10 +319,11 @@ extern "C" int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const 
             slabs[3] = ve, slabs[4] = ve + v_bs, slabs[5] = ve + 2 * v_bs;
             fss[0] = fss[1] = fss[2] = k_fs, fss[3] = fss[4] = fss[5] = v_fs;
         }
-        if (const int rc = tf_head_pack(slabs, fss, ns, send, 1, Kl, S, (int)D, ld, 2, stream)) return rc;
-        if (const int rc = order(rk, st, rk->xs, "tf_rank_pivotal")) return rc;
-        if (const int rc = tf_allgather_rows(rk->comm, send, recv, cnt, ns * SD, dtype, rk->xs)) return rc;
-        if (const int rc = order(rk, rk->xs, st, "tf_rank_pivotal")) return rc;
+        if (const int rc = tf_head_pack_norm(slabs, fss, ns, send, 1, Kl, S, (int)D, ld, 2, piv_loc, inv_loc,
+                                             (int64_t)Kl * S, (int)D, dtype, stream))
+            return rc;
+        // the gather on the caller's stream: the attention needs it at once (no stream hand-over, see above)
+        if (const int rc = tf_allgather_rows(rk->comm, send, recv, cnt, ns * SD, dtype, st)) return rc;
         const int64_t fs_r = ns * SD;
         const E* kb = recv;
         const E* vb = recv + (inject ? 1 : 3) * SD;

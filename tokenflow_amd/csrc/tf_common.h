@@ -45,6 +45,31 @@ __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4
 template <typename T>
 __device__ __forceinline__ float to_f32(T x) { return (float)x; }
 
+// 1 / ||row||_2 of one row of D 16-bit elements, computed by one wave (every lane returns the value): the arithmetic of
+// tf_pivot_inv_norm, shared with the kernels that produce the inverse norms on the side (head pack of the rank
+// executor) so that they are bit-identical to it.
+template <typename T>
+__device__ __forceinline__ float tf_row_inv_norm(const typename T::elem* row, int D, int lane) {
+    const int pieces = D >> 3;
+    float s = 0.f;
+    for (int p = lane; p < pieces; p += 64) {
+        const typename T::vec8 v = __builtin_bit_cast(typename T::vec8, ld16(row + p * 8));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float x = (float)v[i];
+            s = fmaf(x, x, s);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    return 1.0f / sqrtf(s);
+}
+
+// head pack with the pivots' inverse norms on the side (csrc/head_exchange.hip; piv = nullptr: plain tf_head_pack)
+int tf_head_pack_norm(const void* const* slabs, const int64_t* frame_strides, int ns, void* send, int W, int Kl, int S,
+                      int hd, int64_t ld, int elem_bytes, const void* piv, float* inv_norm, int64_t rows, int D, int dtype,
+                      void* stream);
+
 // ---- nearest-neighbour partial results (nn_search.hip -> gather_blend.hip) ----------------------
 // One (best score, index) pair per (pivot-range split, keyframe, target); merged in ascending split
 // order with a strict '>' so the first index wins ties.

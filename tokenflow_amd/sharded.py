@@ -401,18 +401,22 @@ class FrameShard:
                 torch.empty(3, Kl + o, S, D, dtype=dtype, device=device))
 
     def pivotal_block(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool, ext,
-                      mode: Optional[str] = None):
+                      mode: Optional[str] = None, inv_norm: bool = False):
         """The pivotal pass of one block on this rank, for the reference's call order (one pivotal pass over all
         blocks, then the chunk passes): `ext` = `ext_alloc(...)` whose pivot / inverse-norm slots o.. the caller has
         filled.  The attention writes its output into ext's slots o.. in place, then ONE grouped neighbour exchange
         carries the last local keyframe's pivots, inverse norms and attention output to slot 0 of rank r+1 (it has the
         rest of the pivotal pass to arrive; nothing waits for it before the propagation).
+        inv_norm=True: the inverse-norm slots o.. are filled HERE from the pivot slots (callers whose norm1 is not the
+        fused LayerNorm producer; the native executor does it inside its pack launch).
         Returns (pivots ext, inverse norms ext, attention output ext [3(Kl+o),S,D], pending requests) -- the
         arguments of `propagate_all(..., halo_reqs=)`."""
         piv, inv, kfo = ext
         o = 1 if self.world > 1 else 0
         Kl = self.Kl
         S, D = piv.shape[1:]
+        if inv_norm:
+            ops.pivot_inv_norm(piv[o:], out=inv[o:])
         self.pivotal_attention(q_local, k_local, v_local, heads, scale, inject, mode=mode, out4=kfo[:, o:])
         reqs = []
         if self.world > 1:
@@ -558,7 +562,7 @@ class NativeShard(FrameShard):
     other methods are `FrameShard`'s own on the same communicator."""
 
     def __init__(self, K: int, comm, halo_comm=None, attn_split: Optional[bool] = None):
-        super().__init__(K, comm=comm, attn_split=attn_split)
+        super().__init__(K, comm=comm, attn_split=attn_split, halo_comm=halo_comm)
         from . import _lib
         lib = _lib.load()
         h = ctypes.c_void_p()
@@ -595,16 +599,17 @@ class NativeShard(FrameShard):
         return out.view(B, S, D)
 
     def pivotal_block(self, q_local, k_local, v_local, heads: int, scale: float, inject: bool, ext,
-                      mode: Optional[str] = None):
+                      mode: Optional[str] = None, inv_norm: bool = False):
         piv, inv, kfo = ext
         B, S, D = q_local.shape
         Kl = self.Kl
         o = 1 if self.world > 1 else 0
-        slot = self._native(q_local, k_local, v_local, heads, scale, inject, mode, piv, inv, kfo, no_halo=False)
+        slot = self._native(q_local, k_local, v_local, heads, scale, inject, mode, piv, inv, kfo, no_halo=False,
+                            inv_norm=inv_norm)
         reqs = [_SlotWait(self, slot, q_local.device)] if self.world > 1 else []
         return piv, inv, kfo.view(3 * (Kl + o), S, D), reqs
 
-    def _native(self, q_local, k_local, v_local, heads, scale, inject, mode, piv, inv, kfo, no_halo):
+    def _native(self, q_local, k_local, v_local, heads, scale, inject, mode, piv, inv, kfo, no_halo, inv_norm=False):
         from . import _lib
         lib = _lib.load()
         B, S, D = q_local.shape
@@ -637,7 +642,8 @@ class NativeShard(FrameShard):
         slot = self._slot
         if not no_halo:
             self._slot = (slot + 1) % _lib.TF_RANK_SLOTS
-        m = (_lib.TF_RANK_HEADS if mode == "heads" else _lib.TF_RANK_BANK) | (_lib.TF_RANK_NO_HALO if no_halo else 0)
+        m = ((_lib.TF_RANK_HEADS if mode == "heads" else _lib.TF_RANK_BANK) | (_lib.TF_RANK_NO_HALO if no_halo else 0)
+             | (_lib.TF_RANK_INV_NORM if inv_norm else 0))
         rc = lib.tf_rank_pivotal(self._rk, q3.data_ptr(), k3.data_ptr(), v3.data_ptr(), strides,
                                  None if piv is None else piv.data_ptr(), None if inv is None else inv.data_ptr(),
                                  kfo.data_ptr(), S, heads, dh, float(scale), flags, dt, m, slot, ws.data_ptr(),

@@ -4,7 +4,7 @@
 configs 1 and 2 on one GPU, and the two calls of a head-sharded rank of 8 (bank-only on one head group over all
 keyframes; source-only on the rank's own frame, all heads).  Per shape: the streaming form (split + merge allowed), the
 fused kernel in its automatic geometry, and every built geometry (query waves x key groups), with P in one value and
-as hi + lo; HIP events on the launch stream around each call, avg / min over `reps` launches.
+as hi + lo; GPU time per call from HIP-graph replays of 20 back-to-back calls (avg / min over `reps` replays).
 
     python tools/fused_microbench.py [--reps 20] [--only substring]"""
 import argparse
@@ -16,7 +16,34 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from tokenflow_amd import _lib, ops  # noqa: E402
-from attn_microbench import time_it  # noqa: E402
+
+
+def time_it(fn, reps=20, warm=3, batch=20):
+    """GPU time of one call: `batch` calls captured into ONE HIP graph and replayed `reps` times between two events --
+    a single small call issued from Python is host-bound (~20 us of issue time against a 5-30 us kernel)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(batch):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / batch)
+    return sum(ts) / len(ts), min(ts)
+
 
 # (label, K, S, heads, head dim, part)
 SHAPES = [
@@ -32,7 +59,7 @@ SHAPES = [
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -54,7 +81,7 @@ def main():
                     row.append(f"{tag} ERR {str(e)[:40]}")
             t("stream", fused=False)
             t("auto", fused=None)
-            for geom in ((1, 4), (2, 4), (4, 2), (4, 1)):
+            for geom in ((1, 4), (1, 8), (2, 4), (4, 2), (4, 1)):
                 t("%dx%d" % geom, fused=True, hints=_lib.attn_hint(*geom) | _lib.TF_ATTN_NO_PRECISE_P)
                 t("%dx%dp" % geom, fused=True, hints=_lib.attn_hint(*geom) | _lib.TF_ATTN_PRECISE_P)
             print(f"{label:17s} K={K} S={S} h={h} d={d} inj={int(inj)} {fl / 1e9:7.1f} GFLOP | us avg/min: " + " | ".join(row), flush=True)

@@ -16,12 +16,15 @@ for stage in "$@"; do
     alltests)   timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x 2>&1 | tail -40 > $O/all_gpu_tests.txt; tail -15 $O/all_gpu_tests.txt ;;
     fusedbench) timeout 600 python tools/fused_microbench.py > $O/fused_microbench.txt 2>&1; tail -40 $O/fused_microbench.txt ;;
     rankstep)   timeout 600 python tools/rank_step_microbench.py --native --only split,auto > $O/rank_step_native.txt 2>&1; tail -14 $O/rank_step_native.txt
-                timeout 300 python tools/rank_step_microbench.py --native --only onepass,auto > $O/rank_step_native_onepass.txt 2>&1; tail -4 $O/rank_step_native_onepass.txt | head -3 ;;
+                timeout 300 python tools/rank_step_microbench.py --native --only split,auto --no-copies --no-levels > $O/rank_step_native_nocopies.txt 2>&1; tail -3 $O/rank_step_native_nocopies.txt
+                timeout 300 python tools/rank_step_microbench.py --native --only onepass,auto --no-levels > $O/rank_step_native_onepass.txt 2>&1; tail -3 $O/rank_step_native_onepass.txt ;;
     bench)      timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; python -c "import json;d=json.load(open('$O/bench.json'));print(d['ms_per_step'],d['value'],d['roofline']['frac'],d.get('parity',{}).get('attn_linf'),[ (l['attn_linf'],l['attn_linf_fp32_out']) for l in d.get('parity',{}).get('by_level',[])])" ;;
     benchquick) timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-yardstick > $O/bench_quick.json 2> $O/bench_quick.err; python -c "import json;d=json.load(open('$O/bench_quick.json'));print(d['ms_per_step'],d['value'],d['roofline']['frac'],[ (l['attn_linf'],l['attn_linf_fp32_out']) for l in d.get('parity',{}).get('by_level',[])])" ;;
     cfg1)       timeout 600 python bench.py --config cfg1 --steps 50 --warmup 10 --no-cpu-baseline --no-yardstick > $O/bench_cfg1.json 2> $O/bench_cfg1.err; python -c "import json;d=json.load(open('$O/bench_cfg1.json'));print('cfg1',d['ms_per_step'],[ (l['attn_linf'],l['attn_linf_fp32_out']) for l in d.get('parity',{}).get('by_level',[])])"
                 timeout 600 python bench.py --config cfg1 --steps 50 --warmup 10 --graph --no-cpu-baseline --no-yardstick --no-parity > $O/bench_cfg1_graph.json 2> $O/bench_cfg1_graph.err; python -c "import json;d=json.load(open('$O/bench_cfg1_graph.json'));print('cfg1 graph',d['ms_per_step'])" ;;
-    proxy)      for v in 0 1; do timeout 120 tools/ubench/attn_loop_proxy $v >> $O/attn_loop_proxy.txt 2>&1; done; cat $O/attn_loop_proxy.txt ;;
+    proxy)      timeout 300 tools/ubench/attn_loop_proxy > $O/attn_loop_proxy.txt 2>&1; cat $O/attn_loop_proxy.txt ;;
+    ranktimeline) rm -rf /tmp/rt; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/rt -- python $GRAFT_REPO_ROOT/tools/rank_step_microbench.py --native --only split,auto --reps 6 --no-levels > /dev/null 2>$GRAFT_REPO_ROOT/$O/ranktimeline.err )
+                DB=$(find /tmp/rt -name "*_results.db" | head -1); python tools/rocpd_timeline.py $DB --ms 5.6 > $O/rank_timeline.txt; python tools/rocpd_stats.py $DB > $O/rank_kernel_stats.csv; wc -l $O/rank_timeline.txt ;;
     *) echo "unknown stage $stage" ;;
   esac
 done

@@ -77,6 +77,18 @@ class LocalComm:
             self.bytes += sum(t.numel() * t.element_size() for t in send)
 
 
+def latest_driver_ms(default=26.0):
+    """ms_per_step of the newest driver bench record (BENCH_rNN.json at the repository root)."""
+    import glob
+    import json
+    for path in sorted(glob.glob(os.path.join(ROOT, "BENCH_r*.json")), reverse=True):
+        try:
+            return float(json.load(open(path))["parsed"]["ms_per_step"])
+        except Exception:  # noqa: BLE001
+            continue
+    return default
+
+
 def measure(fn, reps, warm):
     for _ in range(warm):
         fn()
@@ -106,9 +118,15 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--link-gbs", type=float, default=50.0, help="assumed achieved rate of one xGMI link, GB/s")
-    ap.add_argument("--single-ms", type=float, default=27.9, help="single-GPU step (driver, round 2)")
+    ap.add_argument("--single-ms", type=float, default=latest_driver_ms(),
+                    help="single-GPU step to quote ratios against (default: ms_per_step of the newest BENCH_r*.json the "
+                         "driver left at the repository root)")
     ap.add_argument("--profile", action="store_true", help="cProfile of the host side of 5 steps (first configuration)")
     ap.add_argument("--only", default="", help="e.g. 'split,auto': run one configuration (split|onepass , auto|heads|bank)")
+    ap.add_argument("--no-levels", action="store_true", help="skip the per-level isolated blocks (profiling runs)")
+    ap.add_argument("--no-copies", action="store_true",
+                    help="--native: the loopback exchanges move nothing (tf_comm_loopback_copies(0)): the rank step with the "
+                         "stand-in copies excluded from the GPU time as well")
     ap.add_argument("--native", action="store_true",
                     help="sharded.NativeShard: the pivotal pass of a block as ONE library call (tf_rank_pivotal) on the "
                          "library's loopback transport (tf_comm_init_loopback: the same wire-less stand-in, in C)")
@@ -123,9 +141,10 @@ def main():
                 continue
             if args.native:
                 from tokenflow_amd.comm import HipComm
-                comm = HipComm.loopback(args.rank, args.world)
+                comm = HipComm.loopback(args.rank, args.world, copies=not args.no_copies)
                 comm.bytes = 0
-                shard = sharded.NativeShard(cfg.K, comm, HipComm.loopback(args.rank, args.world), attn_split=split)
+                shard = sharded.NativeShard(cfg.K, comm, HipComm.loopback(args.rank, args.world, copies=not args.no_copies),
+                                            attn_split=split)
             else:
                 comm = LocalComm(args.rank, args.world)
                 shard = sharded.FrameShard(cfg.K, comm=comm, attn_split=split)
@@ -134,7 +153,7 @@ def main():
             gen = torch.Generator(device=dev).manual_seed(1234 + args.rank)
             blocks = [bench.Block(cfg, lvl, inj, shard, gen, dev) for lvl, inj in workload.BLOCKS]
             modes = [mode or shard.auto_mode(l[2], l[0]) for l in cfg.levels]
-            print(f"=== {'NATIVE executor, ' if args.native else ''}rank {args.rank} of {args.world}, {cfg.name}: Kl={shard.Kl}, attention "
+            print(f"=== {'NATIVE executor, ' if args.native else ''}{'stand-in copies EXCLUDED, ' if args.no_copies else ''}rank {args.rank} of {args.world}, {cfg.name}: Kl={shard.Kl}, attention "
                   f"{'split+merge' if split else 'one-pass (bit-exact)'}, exchange per level {modes}", flush=True)
             if args.profile:
                 import cProfile
@@ -163,7 +182,7 @@ def main():
             if comm.bytes:
                 print(f"  wire: {comm.bytes / 1e6:7.1f} MB sent per rank and step; at {args.link_gbs:.0f} GB/s per link over "
                       f"{min(args.world - 1, 7)} links {wire_us:7.0f} us if nothing overlapped (halo: one link only)")
-            for lvl in range(len(cfg.levels)):
+            for lvl in range(0 if not args.no_levels else len(cfg.levels), len(cfg.levels)):
                 blk = next(b for b in blocks if b.lvl == lvl)
                 for inj in ((False, True) if blk.injected or any(b.injected for b in blocks if b.lvl == lvl) else (False,)):
                     b1 = next((b for b in blocks if b.lvl == lvl and b.injected), blk) if inj else blk
@@ -171,8 +190,7 @@ def main():
 
                     def pivotal():
                         scale = (b1.D // b1.h) ** -0.5
-                        bench.ops.pivot_inv_norm(b1.pivots, out=b1.ext[1][1:])
-                        state["h"] = shard.pivotal_block(b1.q, b1.k, b1.v, b1.h, scale, inj, b1.ext, mode=mode)
+                        state["h"] = shard.pivotal_block(b1.q, b1.k, b1.v, b1.h, scale, inj, b1.ext, mode=mode, inv_norm=True)
 
                     def prop():
                         pe, ie, ke, reqs = state["h"]
