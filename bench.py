@@ -19,7 +19,8 @@ config_pnp.yaml:21); the two states are also timed separately (`ms_per_step_inje
 N > 1: frames are sharded over ranks (tokenflow_amd/sharded.py): the SAME video is split, so scaling is "strong";
 the pivotal-pass exchange (frames <-> heads all-to-all or the single-collective bank all-gather, chosen per block;
 --pivotal-exchange forces one) and the neighbour halo exchange run through torch.distributed (RCCL) inside the
-timed region.  The step then follows the reference's call order: the pivotal pass over all 16 blocks, then the
+timed region.  `value` / `ms_per_step` time the form whose results equal the single-GPU run bit for bit; the split
+form of the rank's attention is timed in a second region and reported as `ms_per_step_split`.  The step then follows the reference's call order: the pivotal pass over all 16 blocks, then the
 propagation of all blocks (the halo of a block travels under the rest of the pivotal pass).
 
 Prints ONE JSON line (rank 0):
@@ -65,18 +66,22 @@ def parse():
     ap.add_argument("--config", default="cfg2", choices=list(workload.CONFIGS))
     ap.add_argument("--pivotal-exchange", default="auto", choices=["auto", "heads", "bank"],
                     help="N > 1: how the pivotal pass is exchanged (sharded.py); auto = heads when they divide")
-    ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo", "hip", "native"],
-                    help="N > 1: auto (default) = native, falling back to nccl if the library's communicators cannot be "
-                         "created; nccl = RCCL through torch.distributed; hip = the exchange steps through "
+    ap.add_argument("--backend", default="nccl", choices=["auto", "nccl", "gloo", "hip", "native"],
+                    help="N > 1: nccl (default) = RCCL through torch.distributed -- the plainest path, and the default until "
+                         "the library's own communicators have run on a multi-GPU node (no such node was available to "
+                         "any round; tools/scale.sh measures both); auto = native, falling back to nccl if the library's "
+                         "communicators cannot be created; hip = the exchange steps through "
                          "the library's C ABI (tf_comm_*: RCCL without torch.distributed on the data path; gloo carries "
                          "only the barrier and the unique id); native = hip plus the pivotal pass of a block as ONE library "
                          "call (tf_rank_pivotal: pack, exchanges, attention, unpack, halo issued by native code; a second "
                          "communicator carries the halo); gloo lets several ranks share one GPU on a development "
                          "box (functional check of the N > 1 path, its timing means nothing)")
     ap.add_argument("--no-attn-split", action="store_true",
-                    help="N > 1: keep the rank's attention in its one-pass form (FrameShard's default: bit-identical to "
-                         "the single-GPU result).  By default the bench lets a rank's small grid split the bank over "
-                         "extra workgroups and merge (attn_split=True: faster, equal within the output rounding)")
+                    help="N > 1: time ONLY the bit-identical form.  By default the timed region runs the rank's attention "
+                         "in the form whose results equal the single-GPU run bit for bit (`value`, `ms_per_step`), and a "
+                         "second timed region of the same length runs the split form (small grids split the key "
+                         "sequence inside / over workgroups and merge: equal within the output rounding) and reports it "
+                         "as `ms_per_step_split`")
     ap.add_argument("--per-chunk", action="store_true",
                     help="issue the propagation one call per chunk (the reference's granularity) instead of one "
                          "call per block over all chunks")
@@ -237,7 +242,7 @@ def other_rooflines(cfg, blocks, w):
          "algorithmic_gflop_per_launch": round(fl_all / 1e9, 1)},
         {"kernel": "nn_search (level 0, ONE chunk against %d keyframes, search + finalize launches: GEMM + fused "
                    "normalisation and argmax; the step itself searches all chunks of a block in one launch, "
-                   "profiles/r02_kernel_stats.csv)" % P,
+                   "profiles/r04_kernel_stats.csv)" % P,
          "bound": "mfma", "achieved": round(fl / t_nn / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
          "frac": round(fl / t_nn / 1e9 / 2500.0, 4), "avg_launch_ms": round(t_nn, 4),
          "algorithmic_gflop_per_launch": round(fl / 1e9, 1)},
@@ -378,7 +383,7 @@ def parity_check(cfg, blocks, w):
     rate of one chunk on sampled targets (tolerance 1e-5 on the fp32 cosine similarity).  The headline figures
     are the worst over the levels; `by_level` keeps each."""
     from oracle import tokenflow_oracle as orc
-    by_level, attn_rows, nn_total = [], 0, 0
+    by_level, f16_levels, attn_rows, nn_total = [], [], 0, 0
     worst_state, worst_state32, worst_ratio = {}, {}, [0.0]
     nn_bad = nn_diff = 0
     K, n = cfg.K, cfg.chunk
@@ -389,38 +394,46 @@ def parity_check(cfg, blocks, w):
         blk = next((b for b in cands if b.injected), cands[0])
         S, D, h = blk.S, blk.D, blk.h
         d = D // h
-        qc, kc, vc = (t.float().cpu().view(3, K, S, h, d) for t in (blk.q, blk.k, blk.v))
         rows = torch.arange(min(3, S - 1), S, max(S // 24, 1))
         worst, worst32, floor16, lvl_ratio = {}, {}, 0.0, 0.0
-        for inject in ((False, True) if cfg.pnp else (False,)):
-            out = ops.ext_attn(blk.q, blk.k, blk.v, h, d ** -0.5, inject).float().cpu().view(3, K, S, h, d)
-            # the same launch with TF_ATTN_OUT_F32: the normalised fp32 accumulator, no 16-bit output rounding
-            out32 = ops.ext_attn(blk.q, blk.k, blk.v, h, d ** -0.5, inject, out_dtype=torch.float32).cpu().view(3, K, S, h, d)
-            err = err32 = ratio = 0.0
-            for b, f, head in [(0, 0, 0), (0, K - 1, h - 1), (1, 0, h // 2), (1, K - 1, 0), (2, K // 2, h - 1), (2, K - 2, 1)]:
-                bq = 0 if (inject and b > 0) else b
-                qr = qc[bq, f, rows, head]
-                if b == 0:
-                    kk, vv = kc[0, f, :, head], vc[0, f, :, head]
-                else:
-                    kk, vv = kc[bq, :, :, head].reshape(K * S, d), vc[b, :, :, head].reshape(K * S, d)
-                pm = torch.softmax(qr @ kk.T * d ** -0.5, dim=-1)
-                ref = pm @ vv                                                    # tokenflow_utils.py:173-179
-                e16 = (out[b, f, rows, head] - ref).abs()
-                err = max(err, float(e16.max()))
-                err32 = max(err32, float((out32[b, f, rows, head] - ref).abs().max()))
-                # the bound the parity tests assert for 16-bit P and output (tests/test_kernels_gpu.py)
-                bound = 2e-4 + 2.0 ** -8 * (ref.abs() + pm @ vv.abs())
-                ratio = max(ratio, float((e16 / bound).max()))
-                # what ANY bf16 tensor holding `ref` is off by at worst: half an ulp = 2^(exponent - 8)
-                floor16 = max(floor16, float(torch.exp2(torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 8).max()))
-            state = "inject" if inject else "plain"
-            worst[state], worst32[state] = err, err32
-            worst_state[state] = max(worst_state.get(state, 0.0), err)
-            worst_state32[state] = max(worst_state32.get(state, 0.0), err32)
-            worst_ratio[0] = max(worst_ratio[0], ratio)
-            lvl_ratio = max(lvl_ratio, ratio)
-            attn_rows += int(len(rows)) * 6
+        f16_16, f16_32 = 0.0, 0.0     # the same problems in f16, the reference's own autocast dtype (run_tokenflow_pnp.py:220)
+        for dt in (torch.bfloat16, torch.float16):
+            dq, dk, dv = ((blk.q, blk.k, blk.v) if dt == torch.bfloat16 else (blk.q.half(), blk.k.half(), blk.v.half()))
+            qc, kc, vc = (t.float().cpu().view(3, K, S, h, d) for t in (dq, dk, dv))
+            for inject in ((False, True) if cfg.pnp else (False,)):
+                out = ops.ext_attn(dq, dk, dv, h, d ** -0.5, inject).float().cpu().view(3, K, S, h, d)
+                # the same launch with TF_ATTN_OUT_F32: the normalised fp32 accumulator, no 16-bit output rounding
+                out32 = ops.ext_attn(dq, dk, dv, h, d ** -0.5, inject, out_dtype=torch.float32).cpu().view(3, K, S, h, d)
+                err = err32 = ratio = 0.0
+                for b, f, head in [(0, 0, 0), (0, K - 1, h - 1), (1, 0, h // 2), (1, K - 1, 0), (2, K // 2, h - 1), (2, K - 2, 1)]:
+                    bq = 0 if (inject and b > 0) else b
+                    qr = qc[bq, f, rows, head]
+                    if b == 0:
+                        kk, vv = kc[0, f, :, head], vc[0, f, :, head]
+                    else:
+                        kk, vv = kc[bq, :, :, head].reshape(K * S, d), vc[b, :, :, head].reshape(K * S, d)
+                    pm = torch.softmax(qr @ kk.T * d ** -0.5, dim=-1)
+                    ref = pm @ vv                                                    # tokenflow_utils.py:173-179
+                    e16 = (out[b, f, rows, head] - ref).abs()
+                    err = max(err, float(e16.max()))
+                    err32 = max(err32, float((out32[b, f, rows, head] - ref).abs().max()))
+                    if dt == torch.bfloat16:
+                        # the bound the parity tests assert for 16-bit P and output (tests/test_kernels_gpu.py)
+                        bound = 2e-4 + 2.0 ** -8 * (ref.abs() + pm @ vv.abs())
+                        ratio = max(ratio, float((e16 / bound).max()))
+                        # what ANY bf16 tensor holding `ref` is off by at worst: half an ulp = 2^(exponent - 8)
+                        floor16 = max(floor16, float(torch.exp2(torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 8).max()))
+                if dt == torch.float16:
+                    f16_16, f16_32 = max(f16_16, err), max(f16_32, err32)
+                    continue
+                state = "inject" if inject else "plain"
+                worst[state], worst32[state] = err, err32
+                worst_state[state] = max(worst_state.get(state, 0.0), err)
+                worst_state32[state] = max(worst_state32.get(state, 0.0), err32)
+                worst_ratio[0] = max(worst_ratio[0], ratio)
+                lvl_ratio = max(lvl_ratio, ratio)
+                attn_rows += int(len(rows)) * 6
+        f16_levels.append({"level": lvl, "attn_linf": round(f16_16, 6), "attn_linf_fp32_out": round(f16_32, 6)})
         # NN search of chunk c on sampled targets
         c = min(3, K - 1)
         nS = n * S
@@ -452,12 +465,19 @@ def parity_check(cfg, blocks, w):
             "tolerance_note": "attn_linf is absolute.  With P and the output in bf16 (8 significand bits; the reference's "
                               "autocast rounds at the same two points in its 16-bit type) the deviation is relative: "
                               "bound = 2e-4 + 2^-8 (|ref| + softmax.|V|), the one the parity tests assert; "
-                              "attn_err_over_bf16_bound <= 1 means inside it.  In absolute terms 1e-3 holds where "
-                              "|out| <= 0.25: at the fine levels (thousands of keys averaged); the short source-branch "
-                              "problems of the coarse levels reach |out| ~ 0.6 on these N(0,1) inputs.  "
-                              "attn_linf_fp32_out = the same launches with TF_ATTN_OUT_F32 (no output rounding)",
+                              "attn_err_over_bf16_bound <= 1 means inside it.  attn_linf_fp32_out = the same launches with "
+                              "TF_ATTN_OUT_F32 (no output rounding): below 1e-3 at EVERY level since round 4 -- frames of "
+                              "<= 256 tokens run in the fused kernel, which carries P as hi + lo bf16 (the rounding of P was "
+                              "what exceeded 1e-3 where a handful of keys is averaged).  What is left in attn_linf at the "
+                              "coarse levels is the rounding of the bf16 OUTPUT itself (half an ulp of |out| ~ 0.5-1: "
+                              "bf16_half_ulp_of_largest_ref), which no bf16 tensor can avoid",
             "nn_mismatch_rate": nn_bad / nn_total, "nn_index_diff_rate": nn_diff / nn_total,
             "nn_targets_checked": nn_total, "by_level": by_level,
+            "f16": {"note": "the same problems with f16 inputs -- the reference's own autocast dtype (run_tokenflow_pnp.py:220): "
+                            "P and the output carry 11 significand bits",
+                    "attn_linf": round(max(l["attn_linf"] for l in f16_levels), 6),
+                    "attn_linf_fp32_out": round(max(l["attn_linf_fp32_out"] for l in f16_levels), 6),
+                    "by_level": f16_levels},
             "reference": "oracle (fp32 CPU restatement pinned to the verbatim reference, tests/golden/)"}
 
 
@@ -518,13 +538,16 @@ def main():
             halo_group = dist.new_group(backend="nccl")      # a second RCCL communicator for the neighbour halo
         elif args.backend == "gloo":
             dist.init_process_group("gloo")
-    split = world > 1 and not args.no_attn_split
-    if world > 1 and args.backend == "native":
-        shard = sharded.NativeShard(cfg.K, hip_comm, halo_comm, attn_split=split)
-    elif world > 1:
-        shard = sharded.FrameShard(cfg.K, comm=hip_comm, attn_split=split, halo_comm=halo_comm, halo_group=halo_group)
-    else:
-        shard = sharded.FrameShard(cfg.K, attn_split=False)
+    def make_shard(split):
+        if world > 1 and args.backend == "native":
+            return sharded.NativeShard(cfg.K, hip_comm, halo_comm, attn_split=split)
+        if world > 1:
+            return sharded.FrameShard(cfg.K, comm=hip_comm, attn_split=split, halo_comm=halo_comm, halo_group=halo_group)
+        return sharded.FrameShard(cfg.K, attn_split=False)
+    # N > 1: `value` is measured on the form that reproduces the single-GPU result bit for bit; the split form is a
+    # second timed region (`ms_per_step_split`)
+    shard = make_shard(False)
+    shard_split = make_shard(True) if world > 1 and not args.no_attn_split else None
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     blocks = [Block(cfg, lvl, inj, shard, gen, dev) for lvl, inj in workload.BLOCKS]
     w = blend_w(cfg.chunk, dev)
@@ -541,8 +564,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step(i, events=None):
-        return run_step(cfg, blocks, shard, i % 2 == 0, w, events, exchange=exchange, per_chunk=args.per_chunk)
+    def step(i, events=None, sh=None):
+        return run_step(cfg, blocks, sh or shard, i % 2 == 0, w, events, exchange=exchange, per_chunk=args.per_chunk)
 
     for i in range(args.warmup):
         step(i)
@@ -572,6 +595,19 @@ def main():
         t = torch.tensor([elapsed], device="cpu" if hip_comm is not None else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    ms_split = None
+    if shard_split is not None:     # the same K steps in the split form (same barriers, max over ranks)
+        for i in range(args.warmup):
+            step(i, sh=shard_split)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, sh=shard_split)
+        barrier()
+        el = time.perf_counter() - t1
+        t = torch.tensor([el], device="cpu" if hip_comm is not None else dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms_split = float(t.item()) / args.steps * 1e3
     if use_graph:                   # roofline bracket: separate eager pass (events cannot be read out of a graph)
         for i in range(2):
             step(i, events)
@@ -630,6 +666,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic",
+        "ms_per_step_split": ms_split and round(ms_split, 3),
         "ms_per_step_inject_on": avg(per_state[True]) and round(avg(per_state[True]), 3),
         "ms_per_step_inject_off": avg(per_state[False]) and round(avg(per_state[False]), 3),
         "config": {"workload": cfg.name + " (hot path: 16 blocks x [ext-attn + NN-search + gather/blend over %d chunks])" % cfg.K,
@@ -642,8 +679,9 @@ def main():
                    "frames sharded over %d GPUs; pivotal pass: %s%s; rank attention %s" % (
                        world, exch_name, ("; one library call per block (tf_rank_pivotal)" if args.backend == "native" else
                                          "; exchanges through the C ABI (tf_comm_*)") if hip_comm is not None else "",
-                       "split over extra workgroups + merge (equal to 1 GPU within the output rounding)"
-                       if shard.attn_split else "one-pass (bit-identical to 1 GPU)"),
+                       "bit-identical to 1 GPU (ms_per_step); ms_per_step_split = small grids split the key sequence and "
+                       "merge (equal within the output rounding)" if shard_split is not None
+                       else "bit-identical to 1 GPU"),
                    "step_algorithmic_tflop": round((fa + fn) / 1e12, 2),
                    "step_tflops_achieved": round((fa + fn) / 1e12 / (ms_per_step * 1e-3), 1)},
         "roofline": plain if plain is not None else dual,
@@ -662,8 +700,9 @@ def main():
             lv = [int(x) for x in args.cpu_sample_levels.split(",") if x != ""]
             out["cpu_baseline"] = cpu_baseline(cfg, lv)
         print(json.dumps(out), flush=True)
-    if isinstance(shard, sharded.NativeShard):
-        shard.close()
+    for sh_ in (shard, shard_split):
+        if isinstance(sh_, sharded.NativeShard):
+            sh_.close()
     for c in (halo_comm, hip_comm):
         if c is not None:
             c.close()

@@ -32,6 +32,10 @@ extern "C" {
 
 #define TF_ABI_VERSION 5
 
+/* Every entry point below is exported with default visibility; the library itself is built with -fvisibility=hidden, so
+ * its exported symbols are exactly the declarations of this header (checked by tests/test_hooks_cpu.py). */
+#define TF_API __attribute__((visibility("default")))
+
 /* element types */
 #define TF_BF16 0
 #define TF_F16 1
@@ -61,10 +65,10 @@ extern "C" {
 #define TF_ERR_WORKSPACE (-5)
 #define TF_ERR_COMM (-6)      /* RCCL not loadable, or a collective failed (tf_last_error has RCCL's message) */
 
-int tf_abi_version(void);
+TF_API int tf_abi_version(void);
 
 /* Thread-local description of the last non-zero return value on this thread. */
-const char* tf_last_error(void);
+TF_API const char* tf_last_error(void);
 
 /* ------------------------------------------------------------------------
  * Extended attention  --  replaces the body of sa_forward.forward between the
@@ -116,9 +120,9 @@ const char* tf_last_error(void);
  *   ws: scratch for the transposed V bank (+ key norms, + split-form partials); size from
  *   tf_ext_attn_workspace_bytes.
  * ------------------------------------------------------------------------ */
-size_t tf_ext_attn_workspace_bytes(int K, int S, int H, int Dh, int dtype);
+TF_API size_t tf_ext_attn_workspace_bytes(int K, int S, int H, int Dh, int dtype);
 
-int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void* out,
+TF_API int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void* out,
                     int K, int Kq, int q_frame0, int S, int H, int Dh, int64_t ld, float scale,
                     int inject, int dtype, void* ws, size_t ws_bytes, void* stream);
 
@@ -131,7 +135,7 @@ int tf_ext_attn_fwd(const void* q, const void* k, const void* v, void* out,
  *   while the bank arrives from an all-gather as dense slabs); out has token stride H*Dh.
  * Branch b of a tensor is addressed as base + b*branch_stride even when a call never touches branch 0 (bank-only
  * calls): pass base = (first touched slab) - b*branch_stride.  tf_ext_attn_fwd is this function with dense strides. */
-int tf_ext_attn_fwd_strided(const void* q, const void* k, const void* v, void* out,
+TF_API int tf_ext_attn_fwd_strided(const void* q, const void* k, const void* v, void* out,
                             int K, int Kq, int q_frame0, int S, int H, int Dh, int64_t ld, const int64_t* strides,
                             float scale, int inject, int dtype, void* ws, size_t ws_bytes, void* stream);
 
@@ -143,10 +147,10 @@ int tf_ext_attn_fwd_strided(const void* q, const void* k, const void* v, void* o
  *   tf_head_unpack:  dst_b[f][s][w*hd ..)     = recv[w][f][b][s][0..hd)            b < nb <= 6 destinations.
  * elem_bytes 2 or 4; hd*elem_bytes and ld*elem_bytes multiples of 16.
  * ------------------------------------------------------------------------ */
-int tf_head_pack(const void* const* slabs, const int64_t* frame_strides, int ns, void* send, int W, int Kl, int S,
+TF_API int tf_head_pack(const void* const* slabs, const int64_t* frame_strides, int ns, void* send, int W, int Kl, int S,
                  int hd, int64_t ld, int elem_bytes, void* stream);
 
-int tf_head_unpack(const void* recv, void* const* dsts, const int64_t* frame_strides, int nb, int W, int Kl, int S,
+TF_API int tf_head_unpack(const void* recv, void* const* dsts, const int64_t* frame_strides, int nb, int W, int Kl, int S,
                    int hd, int64_t ld, int elem_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
@@ -167,12 +171,12 @@ int tf_head_unpack(const void* recv, void* const* dsts, const int64_t* frame_str
  *   ws: scratch for per-split candidates when the pivot range is split over workgroups
  *   (size from tf_nn_search_workspace_bytes, >= 256 bytes).
  * ------------------------------------------------------------------------ */
-int tf_pivot_inv_norm(const void* piv, float* inv_norm, int64_t rows, int D, int dtype,
+TF_API int tf_pivot_inv_norm(const void* piv, float* inv_norm, int64_t rows, int D, int dtype,
                       void* stream);
 
-size_t tf_nn_search_workspace_bytes(int64_t n_tgt, int S, int D, int P);
+TF_API size_t tf_nn_search_workspace_bytes(int64_t n_tgt, int S, int D, int P);
 
-int tf_nn_search(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx,
+TF_API int tf_nn_search(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx,
                  int64_t n_tgt, int S, int D, int P, int kf0, int kf1, int dtype,
                  void* ws, size_t ws_bytes, void* stream);
 
@@ -192,7 +196,7 @@ int tf_nn_search(const void* tgt, const void* piv, const float* inv_norm, int32_
  *            `out` is bit-identical to the reference's.
  *   P == 1:  out = a1 + resid  (fp32 add, rounded to out_dtype).
  * ------------------------------------------------------------------------ */
-int tf_gather_blend(const void* kf_out, const int32_t* idx, const float* w, const void* resid,
+TF_API int tf_gather_blend(const void* kf_out, const int32_t* idx, const float* w, const void* resid,
                     void* out, int K, int n, int S, int D, int P, int kf0, int kf1,
                     int in_dtype, int res_dtype, int out_dtype, void* stream);
 
@@ -205,9 +209,9 @@ int tf_gather_blend(const void* kf_out, const int32_t* idx, const float* w, cons
  * Results are bit-identical to the two separate calls.  n_tgt = n*S; arguments as
  * in the two functions above; `search_dtype` is the dtype of tgt and piv.
  * ------------------------------------------------------------------------ */
-size_t tf_nn_gather_blend_workspace_bytes(int64_t n_tgt, int S, int D, int P);
+TF_API size_t tf_nn_gather_blend_workspace_bytes(int64_t n_tgt, int S, int D, int P);
 
-int tf_nn_gather_blend(const void* tgt, const void* piv, const float* inv_norm,
+TF_API int tf_nn_gather_blend(const void* tgt, const void* piv, const float* inv_norm,
                        const void* kf_out, const float* w, const void* resid, void* out,
                        int K, int n, int S, int D, int P, int kf0, int kf1,
                        int search_dtype, int in_dtype, int res_dtype, int out_dtype,
@@ -229,9 +233,9 @@ int tf_nn_gather_blend(const void* tgt, const void* piv, const float* inv_norm,
  *   Results are bit-identical to C calls of tf_nn_gather_blend.  C = 1 with first_single is tf_nn_gather_blend(P = 1).
  *   w : float [n], as tf_gather_blend.
  * ------------------------------------------------------------------------ */
-size_t tf_nn_gather_blend_chunks_workspace_bytes(int64_t n_tgt_chunk, int S, int D, int C);
+TF_API size_t tf_nn_gather_blend_chunks_workspace_bytes(int64_t n_tgt_chunk, int S, int D, int C);
 
-int tf_nn_gather_blend_chunks(const void* tgt, const void* piv, const float* inv_norm, const void* kf_out,
+TF_API int tf_nn_gather_blend_chunks(const void* tgt, const void* piv, const float* inv_norm, const void* kf_out,
                               const float* w, const void* resid, void* out, int K, int n, int C, int S, int D,
                               int slot0, int first_single, int search_dtype, int in_dtype, int res_dtype,
                               int out_dtype, int single_dtype, void* ws, size_t ws_bytes, void* stream);
@@ -247,13 +251,13 @@ int tf_nn_gather_blend_chunks(const void* tgt, const void* piv, const float* inv
  * D <= 1536 (TF_ERR_DTYPE otherwise: issue the two calls).  gamma, beta: [D] of w_dtype or NULL.  Workspace as the
  * unfused calls.
  * ------------------------------------------------------------------------ */
-int tf_nn_gather_blend_norm(const void* tgt, const void* piv, const float* inv_norm, const void* kf_out,
+TF_API int tf_nn_gather_blend_norm(const void* tgt, const void* piv, const float* inv_norm, const void* kf_out,
                             const float* w, const void* resid, void* out, int K, int n, int S, int D, int P, int kf0,
                             int kf1, int search_dtype, int in_dtype, int res_dtype, int out_dtype, const void* gamma,
                             const void* beta, float eps, int w_dtype, void* norm_out, int norm_dtype, void* ws,
                             size_t ws_bytes, void* stream);
 
-int tf_nn_gather_blend_chunks_norm(const void* tgt, const void* piv, const float* inv_norm, const void* kf_out,
+TF_API int tf_nn_gather_blend_chunks_norm(const void* tgt, const void* piv, const float* inv_norm, const void* kf_out,
                                    const float* w, const void* resid, void* out, int K, int n, int C, int S, int D,
                                    int slot0, int first_single, int search_dtype, int in_dtype, int res_dtype,
                                    int out_dtype, int single_dtype, const void* gamma, const void* beta, float eps,
@@ -272,7 +276,7 @@ int tf_nn_gather_blend_chunks_norm(const void* tgt, const void* piv, const float
  *   inv_norm : float [rows] or NULL:  1 / ||out[r]||_2 of the ROUNDED output row -- what
  *              tf_pivot_inv_norm would compute from the stored pivots (util.py:67).
  * ------------------------------------------------------------------------ */
-int tf_layer_norm(const void* x, const void* gamma, const void* beta, void* out, float* inv_norm,
+TF_API int tf_layer_norm(const void* x, const void* gamma, const void* beta, void* out, float* inv_norm,
                   int64_t rows, int D, float eps, int in_dtype, int w_dtype, int out_dtype,
                   void* stream);
 
@@ -282,7 +286,7 @@ int tf_layer_norm(const void* x, const void* gamma, const void* beta, void* out,
  *   out[r]     = LayerNorm(sum_out[r])                   (as tf_layer_norm, on the ROUNDED sum)
  * a, b, sum_out: [rows, D] of a_dtype / b_dtype / sum_dtype.  Results are bit-identical to the add followed by
  * tf_layer_norm. */
-int tf_add_layer_norm(const void* a, const void* b, void* sum_out, const void* gamma, const void* beta, void* out,
+TF_API int tf_add_layer_norm(const void* a, const void* b, void* sum_out, const void* gamma, const void* beta, void* out,
                       int64_t rows, int D, float eps, int a_dtype, int b_dtype, int sum_dtype, int w_dtype,
                       int out_dtype, void* stream);
 
@@ -295,7 +299,7 @@ int tf_add_layer_norm(const void* a, const void* b, void* sum_out, const void* g
  * Same operation order and the same per-op rounding to `dtype` as the reference's sequence (fp32 scalars, no FMA,
  * IEEE division): bit-identical to it in f32 / f16 / bf16.
  * ------------------------------------------------------------------------ */
-int tf_ddim_step(const void* x, const void* eps, void* out, int64_t n, float mu_a, float sigma_a, float mu_b,
+TF_API int tf_ddim_step(const void* x, const void* eps, void* out, int64_t n, float mu_a, float sigma_a, float mu_b,
                  float sigma_b, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------
@@ -303,7 +307,7 @@ int tf_ddim_step(const void* x, const void* eps, void* out, int64_t n, float mu_
  *   x viewed as [3, elems_per_branch]:  x[1] = x[0];  x[2] = x[0]   (in place)
  * elem_bytes = bytes per element; elems_per_branch*elem_bytes multiple of 16.
  * ------------------------------------------------------------------------ */
-int tf_inject_copy(void* x, int64_t elems_per_branch, int elem_bytes, void* stream);
+TF_API int tf_inject_copy(void* x, int64_t elems_per_branch, int elem_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Multi-GPU exchange steps over RCCL (one process per GPU).  The reference is single-process (no
@@ -328,8 +332,8 @@ int tf_inject_copy(void* x, int64_t elems_per_branch, int elem_bytes, void* stre
  * handed to the others by the host (file, socket, MPI ...).
  * ------------------------------------------------------------------------ */
 typedef struct tf_comm tf_comm;
-int tf_comm_unique_id(void* id_out_128_bytes);
-int tf_comm_init(const void* unique_id_128_bytes, int rank, int world, tf_comm** comm_out);
+TF_API int tf_comm_unique_id(void* id_out_128_bytes);
+TF_API int tf_comm_init(const void* unique_id_128_bytes, int rank, int world, tf_comm** comm_out);
 
 /* Two more transports behind the same exchange entry points (no RCCL needed for either):
  *   tf_comm_init_hooks     a host-provided transport -- the exchanges are handed to the function table (sizes in
@@ -352,20 +356,20 @@ typedef struct tf_comm_hooks {
                     void* const* recv, const int64_t* recv_bytes, int n_recv, int recv_peer, void* stream);
     void* user;
 } tf_comm_hooks;
-int tf_comm_init_hooks(const tf_comm_hooks* hooks, int rank, int world, tf_comm** comm_out);
-int tf_comm_init_loopback(int rank, int world, tf_comm** comm_out);
+TF_API int tf_comm_init_hooks(const tf_comm_hooks* hooks, int rank, int world, tf_comm** comm_out);
+TF_API int tf_comm_init_loopback(int rank, int world, tf_comm** comm_out);
 /* loopback only: enabled = 0 makes every exchange a no-op (nothing moves, nothing is enqueued) -- the rank's launch sequence
  * with the stand-in copies taken out of the timing as well; buffers that an exchange would have filled keep their contents */
-int tf_comm_loopback_copies(tf_comm* comm, int enabled);
-int tf_comm_destroy(tf_comm* comm);
-int tf_comm_rank(const tf_comm* comm);
-int tf_comm_world(const tf_comm* comm);
-int tf_allgather_kv(tf_comm* comm, const void* local, void* bank, int64_t elems_per_rank, int dtype, void* stream);
-int tf_allgather_rows(tf_comm* comm, const void* local, void* bank, const int64_t* rows, int64_t row_elems, int dtype,
+TF_API int tf_comm_loopback_copies(tf_comm* comm, int enabled);
+TF_API int tf_comm_destroy(tf_comm* comm);
+TF_API int tf_comm_rank(const tf_comm* comm);
+TF_API int tf_comm_world(const tf_comm* comm);
+TF_API int tf_allgather_kv(tf_comm* comm, const void* local, void* bank, int64_t elems_per_rank, int dtype, void* stream);
+TF_API int tf_allgather_rows(tf_comm* comm, const void* local, void* bank, const int64_t* rows, int64_t row_elems, int dtype,
                       void* stream);
-int tf_all_to_all_rows(tf_comm* comm, const void* send, void* recv, const int64_t* send_rows, const int64_t* recv_rows,
+TF_API int tf_all_to_all_rows(tf_comm* comm, const void* send, void* recv, const int64_t* send_rows, const int64_t* recv_rows,
                        int64_t row_elems, int dtype, void* stream);
-int tf_sendrecv_pivot(tf_comm* comm, const void* const* send, const int64_t* send_elems, int n_send, int send_peer,
+TF_API int tf_sendrecv_pivot(tf_comm* comm, const void* const* send, const int64_t* send_elems, int n_send, int send_peer,
                       void* const* recv, const int64_t* recv_elems, int n_recv, int recv_peer, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------
@@ -408,15 +412,15 @@ int tf_sendrecv_pivot(tf_comm* comm, const void* const* send, const int64_t* sen
                                 instead of the caller in a launch of its own */
 #define TF_RANK_SLOTS 64
 typedef struct tf_rank tf_rank;
-int tf_rank_create(tf_comm* comm, tf_comm* halo_comm, int K, tf_rank** rank_out);
-int tf_rank_destroy(tf_rank* rk);
-int tf_rank_local_keyframes(const tf_rank* rk);
-int tf_rank_first_keyframe(const tf_rank* rk);
-size_t tf_rank_pivotal_workspace_bytes(const tf_rank* rk, int S, int H, int Dh, int dtype);
-int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const void* v, const int64_t* strides, void* piv_ext,
+TF_API int tf_rank_create(tf_comm* comm, tf_comm* halo_comm, int K, tf_rank** rank_out);
+TF_API int tf_rank_destroy(tf_rank* rk);
+TF_API int tf_rank_local_keyframes(const tf_rank* rk);
+TF_API int tf_rank_first_keyframe(const tf_rank* rk);
+TF_API size_t tf_rank_pivotal_workspace_bytes(const tf_rank* rk, int S, int H, int Dh, int dtype);
+TF_API int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const void* v, const int64_t* strides, void* piv_ext,
                     float* inv_ext, void* kfo_ext, int S, int H, int Dh, float scale, int flags, int dtype, int mode,
                     int slot, void* ws, size_t ws_bytes, void* stream);
-int tf_rank_halo_wait(tf_rank* rk, int slot, void* stream);
+TF_API int tf_rank_halo_wait(tf_rank* rk, int slot, void* stream);
 
 #ifdef __cplusplus
 }

@@ -313,6 +313,13 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name)
     assert lib.tf_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define TF_ABI_VERSION (\d+)", hdr).group(1))
+    # ... and NOTHING else with the library's prefix (built with -fvisibility=hidden: internal C++ helpers stay inside)
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    syms = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in syms.splitlines() if " T " in line or " W " in line}
+    assert {n for n in exported if "tf_" in n} == declared, {n for n in exported if "tf_" in n} ^ declared
 
 
 @pytest.mark.parametrize("dtype,sfx", [(torch.float32, ""), (torch.float16, "_f16")])

@@ -25,6 +25,19 @@ for stage in "$@"; do
     proxy)      timeout 300 tools/ubench/attn_loop_proxy > $O/attn_loop_proxy.txt 2>&1; cat $O/attn_loop_proxy.txt ;;
     ranktimeline) rm -rf /tmp/rt; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/rt -- python $GRAFT_REPO_ROOT/tools/rank_step_microbench.py --native --only split,auto --reps 6 --no-levels > /dev/null 2>$GRAFT_REPO_ROOT/$O/ranktimeline.err )
                 DB=$(find /tmp/rt -name "*_results.db" | head -1); python tools/rocpd_timeline.py $DB --ms 5.6 > $O/rank_timeline.txt; python tools/rocpd_stats.py $DB > $O/rank_kernel_stats.csv; wc -l $O/rank_timeline.txt ;;
+    ktrace)     rm -rf /tmp/kt; ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-parity --no-yardstick --steps 10 --warmup 2 > $GRAFT_REPO_ROOT/$O/bench_traced.json 2>/dev/null )
+                python tools/rocpd_stats.py $(find /tmp/kt -name "*_results.db" | head -1) > $O/kernel_stats.csv; head -8 $O/kernel_stats.csv | cut -c1-200 ;;
+    pmc)        for c in FETCH_SIZE WRITE_SIZE; do rm -rf /tmp/pmc_$c; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -- python $GRAFT_REPO_ROOT/tools/attn_microbench.py 8,4096,8,40 > /dev/null 2>&1 )
+                  python tools/rocpd_pmc.py $(find /tmp/pmc_$c -name "*_results.db" | head -1) | grep -v "at::native" > $O/pmc_attn_$c.csv; done
+                for grp in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+                  rm -rf /tmp/sq; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $grp -d /tmp/sq -- python $GRAFT_REPO_ROOT/tools/attn_microbench.py 8,4096,8,40 8,256,8,160 > /dev/null 2>&1 )
+                  python tools/rocpd_pmc.py $(find /tmp/sq -name "*_results.db" | head -1) | grep -v "at::native\|vt_pack" >> $O/pmc_attn_sq.csv; done
+                head -3 $O/pmc_attn_FETCH_SIZE.csv | cut -c1-200 ;;
+    cfg1trace)  rm -rf /tmp/kt1; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt1 -- python $GRAFT_REPO_ROOT/bench.py --config cfg1 --no-cpu-baseline --no-parity --no-yardstick --steps 40 --warmup 5 > /dev/null 2>&1 )
+                python tools/rocpd_stats.py $(find /tmp/kt1 -name "*_results.db" | head -1) > $O/cfg1_kernel_stats.csv; head -30 $O/cfg1_kernel_stats.csv | cut -c1-190 ;;
+    othercfgs)  for cfg in cfg4 cfg5; do timeout 600 python bench.py --config $cfg --no-cpu-baseline --no-yardstick --steps 3 --warmup 1 > $O/bench_$cfg.json 2>$O/bench_$cfg.err; python -c "import json;d=json.load(open('$O/bench_$cfg.json'));print('$cfg',d['ms_per_step'],d['parity']['attn_linf'],d['parity']['attn_linf_fp32_out'],d['parity']['nn_mismatch_rate'])"; done ;;
+    hooks)      for a in "" "--graph" "--graph --all-chunks"; do timeout 600 python tools/hooks_bench.py cfg2 6 $a >> $O/hooks_bench.txt 2>/dev/null; done; cat $O/hooks_bench.txt ;;
+    gloo8)      timeout 900 python bench.py --gpus 8 --backend gloo --steps 2 --warmup 1 > $O/bench_gloo8.txt 2>&1; tail -c 1500 $O/bench_gloo8.txt ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
