@@ -90,6 +90,12 @@ def parse():
                          "replays (launch-bound configurations: cfg1); the roofline bracket is then measured in a "
                          "separate eager pass after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-ref-l0", action="store_true",
+                    help="--cpu-baseline-only with the reference mounted: run level 0 for real (minutes, ~13 GB)")
+    ap.add_argument("--cpu-baseline-only", action="store_true",
+                    help="run ONLY the cpu_baseline leg and print it (no GPU needed): with the reference tree mounted "
+                         "($TOKENFLOW_REFERENCE, default /root/reference) this times the verbatim reference hooks "
+                         "(kind = 'reference'), else the oracle port")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-yardstick", action="store_true")
     ap.add_argument("--cpu-sample-levels", default="0,1,2,3")
@@ -377,6 +383,70 @@ def cpu_baseline(cfg, levels):
                         + "; ".join(parts) + ")"))
 
 
+def cpu_baseline_reference(cfg, levels, full_l0=False):
+    """`cpu_baseline` with kind = "reference": the VERBATIM hooks of omerbt/TokenFlow (tokenflow_utils.py, loaded unmodified
+    by oracle/ref_loader.py from $TOKENFLOW_REFERENCE, default /root/reference) on this host's cores, fp32 -- only where
+    the reference tree is mounted (the build container; a GPU box ships the repository alone and reports the port).
+    Per sampled level ONE block: the pivotal pass's attention through the reference's own `sa_forward` closure on the
+    whole 3K-frame batch (stand-in projections that return the pre-generated q / k / v, as oracle/make_golden.py drives
+    it), and ONE chunk pass of the reference's `TokenFlowBlock.forward` propagation branch (chunk 1: two keyframes).
+    Level 0's attention (minutes on 8 cores, ~13 GB of score matrices) is extrapolated from level 1 by the ratio of the
+    materialised score matrices (S^2: the reference's bmm -> softmax -> bmm is bound by them, not by the flops) unless
+    --cpu-ref-l0 runs it for real; the sample says which."""
+    from oracle import make_golden as mg
+    from oracle import ref_loader
+    from tests import fake_diffusers as fd
+    tfu, _util = ref_loader.load()
+    torch.set_num_threads(usable_cores())
+    K, n, C = cfg.K, cfg.chunk, cfg.K
+    g = torch.Generator().manual_seed(0)
+    total, t_spent, parts, t_attn_by_level = 0.0, 0.0, [], {}
+    for lvl in sorted(set(levels) | {1}, reverse=True):
+        S, D, h = cfg.levels[lvl]
+        nblk = sum(1 for l, _ in workload.BLOCKS if l == lvl)
+        if lvl == 0 and not full_l0:
+            S1, D1, h1 = cfg.levels[1]
+            t_attn = t_attn_by_level[1] * (S / S1) ** 2 * h / h1
+            note = "attn %.1fs extrapolated from level 1 by score-matrix size (S^2)" % t_attn
+        else:
+            q, k, v = (torch.randn(3 * K, S, D, generator=g) for _ in range(3))
+            blk = fd.BasicTransformerBlock(D, h)
+            blk.attn1 = mg.CoreAttention(q, k, v, h)
+            tfu.register_extended_attention_pnp(mg._OneBlock(blk), [])
+            blk.attn1.t = 1
+            with torch.no_grad():
+                t0 = time.perf_counter()
+                blk.attn1.forward(torch.zeros(3 * K, S, D))
+                t_attn = time.perf_counter() - t0
+            t_spent += t_attn
+            note = "attn %.2fs" % t_attn
+        t_attn_by_level[lvl] = t_attn
+        if lvl not in levels:
+            continue
+        Sp = S if (lvl or full_l0) else cfg.levels[1][0]   # the chunk pass is timed at the level's own size except level 0 ...
+        piv = torch.randn(3, K, Sp, D, generator=g)
+        kf_out = torch.randn(3 * K, Sp, D, generator=g)
+        hidden = torch.randn(3 * n, Sp, D, generator=g)
+        pblk = mg._IdBlock(D)
+        pblk.__class__ = tfu.make_tokenflow_attention_block(pblk.__class__)
+        pblk.pivot_hidden_states, pblk.kf_attn_output, pblk.pivotal_pass, pblk.batch_idx = piv, kf_out, False, 1
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            pblk.forward(hidden.clone())
+            t_chunk = time.perf_counter() - t0
+        t_spent += t_chunk
+        if lvl == 0 and not full_l0:              # ... whose NN search scales with S^2 (4x S: 16x), the gather with S
+            t_chunk *= (S / Sp) ** 2
+            note += ", chunk pass extrapolated from level 1's size by S^2"
+        total += nblk * (t_attn + (C - 0.5) * t_chunk)
+        parts.append(f"L{lvl}: {note}, chunk pass {t_chunk:.2f}s")
+    return dict(value=cfg.frames / total, unit="frames/s", cores=torch.get_num_threads(), kind="reference",
+                sample=("VERBATIM reference hooks (tokenflow_utils.py of omerbt/TokenFlow through oracle/ref_loader.py; fp32 "
+                        "torch CPU): per level one block -- sa_forward on the whole 3K-frame batch and one two-keyframe chunk "
+                        "pass of TokenFlowBlock.forward -- scaled by blocks and chunks to a full step "
+                        f"({total:.1f} s/step from {t_spent:.1f} s of single runs; " + "; ".join(parts) + ")"))
+
+
 def parity_check(cfg, blocks, w):
     """In-run parity, ONE BLOCK PER LEVEL (rank 0, N = 1): attention L_inf against the fp32 oracle on sampled
     query rows of six (branch, frame, head) problems, with and without injection; tie-aware NN index mismatch
@@ -496,8 +566,23 @@ def self_launch(args):
     os.execv(sys.executable, cmd)
 
 
+def cpu_leg(cfg, levels, full_l0=False):
+    """The reference itself where its tree is mounted, else the oracle port."""
+    try:
+        from oracle import ref_loader
+        if ref_loader.available():
+            return cpu_baseline_reference(cfg, levels, full_l0)
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] reference-timed CPU baseline unavailable ({e}); timing the oracle port", file=sys.stderr)
+    return cpu_baseline(cfg, levels)
+
+
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        lv = [int(x) for x in args.cpu_sample_levels.split(",") if x != ""]
+        print(json.dumps({"cpu_baseline": cpu_leg(workload.CONFIGS[args.config], lv, args.cpu_ref_l0)}), flush=True)
+        return
     # before the HIP runtime initialises: the host driver of this pool only supports dmabuf IPC (RCCL between processes)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -698,7 +783,7 @@ def main():
             out["yardstick"]["power_state"] = power_state(blocks)
         if world == 1 and not args.no_cpu_baseline:
             lv = [int(x) for x in args.cpu_sample_levels.split(",") if x != ""]
-            out["cpu_baseline"] = cpu_baseline(cfg, lv)
+            out["cpu_baseline"] = cpu_leg(cfg, lv)
         print(json.dumps(out), flush=True)
     for sh_ in (shard, shard_split):
         if isinstance(sh_, sharded.NativeShard):

@@ -134,6 +134,8 @@ def test_ext_attn_shapes(K, S, h, d, inject, no_split, fused, monkeypatch):
     """Ragged S (not a multiple of 64 / 128), single keyframe, many heads, K > 12.  These grids are small: by default
     they run in the fused small-problem kernel; fused=False keeps the streaming kernels, where the bank problems run in
     the split form (runs of bank frames + merge) unless no_split forces the one-pass form on the same inputs."""
+    if fused is None and no_split and S > 256:
+        pytest.skip("larger frames in one-pass mode run the streaming kernels whatever `fused` says: covered by fused=False")
     ops = _ops()
     monkeypatch.setattr(ops, "NO_SPLIT", no_split)
     g = torch.Generator().manual_seed(K * 1000 + S + d)

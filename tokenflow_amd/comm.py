@@ -172,11 +172,27 @@ def bootstrap(rank: int, world: int, n: int = 1, group=None, make=None):
     """Create `n` communicators on every rank of a torch.distributed group that is used as the control plane only
     (gloo: unique ids out, one agreement flag back; no tensor of the path touches it).  Every rank returns the same
     kind of result: (list of n communicators, None), or (None, reason) when ANY rank failed to create one -- no rank
-    is left holding half a set, and nobody blocks in a collective the others never enter.
+    is left holding half a set.  A pre-flight round first agrees that EVERY rank can load RCCL and reach its device
+    (the failures that are local to one rank: a missing library, a bad device); only then do the ranks enter
+    ncclCommInitRank, which is itself collective -- a rank that dies INSIDE it can still leave the others waiting
+    there (RCCL's own timeout applies); what the agreement flags exclude is a rank that never enters it.
     make(unique_id, rank, world) -> communicator; default `HipComm` (RCCL through the C ABI)."""
     import torch.distributed as dist
     make = make or HipComm
     comms, why = [], None
+    pre = None
+    if make is HipComm:
+        try:
+            HipComm.unique_id()             # dlopen of librccl + every symbol, on THIS rank
+            torch.cuda.current_device()
+        except Exception as e:  # noqa: BLE001
+            pre = str(e)
+        ok = torch.tensor([0 if pre else 1])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if not int(ok.item()):
+            reasons = [None] * world
+            dist.all_gather_object(reasons, pre, group=group)
+            return None, next((r for r in reasons if r), "a rank failed its RCCL pre-flight")
     for _ in range(n):
         uid, err = [None], None
         if rank == 0:

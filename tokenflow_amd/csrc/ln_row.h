@@ -82,7 +82,10 @@ __device__ __forceinline__ float ln_row_finish(const float (&v)[NP][8], int lr, 
 #pragma unroll
             for (int i = 0; i < 8; ++i) s += v[j][i];
         }
-    const float mean = ln_row_sum<LPR>(s) * inv_d;
+    // __fmul_rn: a multiply the compiler may NOT contract with the subtractions below into an fma -- this header is
+    // compiled into translation units with different -ffp-contract settings (gather_blend.o: off, layer_norm.o: the
+    // default), and the fused-norm forms must stay bit-identical to tf_layer_norm in both
+    const float mean = __fmul_rn(ln_row_sum<LPR>(s), inv_d);
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < NP; ++j)

@@ -401,12 +401,34 @@ FUSE_NORMS = os.environ.get("TOKENFLOW_FUSED_NORMS", "all")
 FUSE_GATHER_NORM = os.environ.get("TOKENFLOW_FUSED_GATHER_NORM", "1") not in ("", "0")
 
 
-def _block_norm(mod: torch.nn.Module, x: torch.Tensor, want_inv_norm: bool = False, which: str = "norm1"):
-    """(LayerNorm(x), 1/||row|| or None) through the fused kernel when it applies, else the module itself."""
+def _block_norm(mod: torch.nn.Module, x: torch.Tensor, want_inv_norm: bool = False, which: str = "norm1", dest=None):
+    """(LayerNorm(x), 1/||row|| or None) through the fused kernel when it applies, else the module itself.
+    dest(dtype) -> (out, inv_out): destination tensors for the fused kernel (the sharded pivotal pass hands out views
+    of the block's halo-extended state, so that the norm writes the pivots and their inverse norms in place)."""
     dt = _fused_norm_dtype(mod, x) if (FUSE_NORMS == "all" or FUSE_NORMS == which) else None
     if dt is None:
         return mod(x), None
-    return ops.layer_norm(x, mod.weight, mod.bias, mod.eps, dt, want_inv_norm)
+    out, inv_out = dest(dt) if dest is not None else (None, None)
+    return ops.layer_norm(x, mod.weight, mod.bias, mod.eps, dt, want_inv_norm, out=out, inv_out=inv_out)
+
+
+def _shard_state(block, shard, S: int, D: int, dtype, device):
+    """The block's halo-extended propagation state on a sharded rank, allocated ONCE per block and shape and reused
+    step after step (a step's chunk passes are done with it before the next pivotal pass writes it):
+      norm [1 + 3*Kl, S, D]   slot 0 = the left neighbour's last keyframe, then norm1's output of the pivotal pass,
+                              branch-major -- so the first Kl + 1 slots ARE the halo-extended pivots, written by the
+                              norm itself;
+      inv  [1 + 3*Kl, S]      the same for the rows' inverse norms;
+      kfo  [3, Kl + 1, S, D]  cached attention output (after to_out) with the neighbour's slot in front."""
+    key = (shard.Kl, S, D, dtype, device)
+    st = block.__dict__.get("_tf_shard_state")
+    if st is None or st[0] != key:
+        Kl = shard.Kl
+        st = (key, torch.empty(1 + 3 * Kl, S, D, dtype=dtype, device=device),
+              torch.empty(1 + 3 * Kl, S, dtype=torch.float32, device=device),
+              torch.empty(3, Kl + 1, S, D, dtype=dtype, device=device))
+        block.__dict__["_tf_shard_state"] = st
+    return st[1], st[2], st[3]
 
 
 def _add_norm(mod: torch.nn.Module, a: torch.Tensor, h: torch.Tensor, which: str):
@@ -469,7 +491,14 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
                 norm_hidden_states, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.norm1(
                     hidden_states, timestep, class_labels, hidden_dtype=hidden_states.dtype)
             else:   # row f2: LayerNorm emits the 16-bit rows the kernels read (+ the pivots' inverse norms)
-                norm_hidden_states, norm_inv = _block_norm(self.norm1, hidden_states, bool(self.pivotal_pass))
+                dest = None
+                shard0 = _active_shard(self) if self.pivotal_pass else None
+                if shard0 is not None and n_frames == shard0.Kl and hidden_states.is_cuda:
+                    # sharded pivotal pass: norm1 writes straight into the block's halo-extended state
+                    def dest(dt, _s=shard0):
+                        nb, ib, _ = _shard_state(self, _s, sequence_length, dim, dt, hidden_states.device)
+                        return nb[1:].view(3, n_frames, sequence_length, dim), ib[1:].view(3, n_frames, sequence_length)
+                norm_hidden_states, norm_inv = _block_norm(self.norm1, hidden_states, bool(self.pivotal_pass), dest=dest)
             norm_hidden_states = norm_hidden_states.view(3, n_frames, sequence_length, dim)
 
             cross_attention_kwargs = cross_attention_kwargs if cross_attention_kwargs is not None else {}
@@ -487,19 +516,36 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
                 self._tf_pivot_inv_norm = (norm_inv.view(3, n_frames, sequence_length)[0] if norm_inv is not None
                                            else ops.pivot_inv_norm(self._tf_pivots))   # [K,S] fp32
                 shard = _active_shard(self)
+                inplace = False
                 if shard is not None:
                     if n_frames != shard.Kl:
                         raise ValueError(f"pivotal pass with {n_frames} keyframes per branch on a rank that owns "
                                          f"{shard.Kl} (register_frame_shard)")
-                    # the pivots' half of the neighbour halo does not depend on the attention: it travels under it
-                    halo = shard.halo_start(self._tf_pivots, self._tf_pivot_inv_norm.contiguous())
+                    st = self.__dict__.get("_tf_shard_state")
+                    # in place: norm1 has written the pivots and inverse norms into slots 1.. of the halo-extended
+                    # state (the fused LayerNorm path); else (AdaLayerNorm, fp32 models) the two-exchange form, whose
+                    # pivots' half does not depend on the attention and travels under it
+                    inplace = (norm_inv is not None and st is not None
+                               and norm_hidden_states.data_ptr() == st[1][1:].data_ptr())
+                    if not inplace:
+                        halo = shard.halo_start(self._tf_pivots, self._tf_pivot_inv_norm.contiguous())
                 self.attn_output = self.attn1(
                     norm_hidden_states.view(batch_size, sequence_length, dim),
                     encoder_hidden_states=encoder_hidden_states if self.only_cross_attention else None,
                     **cross_attention_kwargs)
                 self.kf_attn_output = self.attn_output
-                if shard is not None:   # (pivots, inverse norms, attention output) with the neighbour's slot in front,
-                    # and the pending requests of the exchange: the first chunk pass waits for them
+                if shard is not None and inplace:
+                    # ONE grouped exchange per block on the cached state: pivots / inverse norms were written by norm1,
+                    # the to_out-projected attention output takes one copy into its slots (to_out is the model's own
+                    # Linear: its output tensor is torch's); no allocation, no other copy
+                    nb, ib, kfo = st[1], st[2], st[3]
+                    Kl = shard.Kl
+                    kfo[:, 1:].copy_(self.kf_attn_output.reshape(3, Kl, sequence_length, dim))
+                    piv_e, inv_e = nb[:Kl + 1], ib[:Kl + 1]
+                    reqs = shard.halo_block(piv_e, inv_e, kfo)
+                    self.__dict__["_tf_halo"] = (piv_e, inv_e, kfo.view(3 * (Kl + 1), sequence_length, dim), reqs)
+                elif shard is not None:   # (pivots, inverse norms, attention output) with the neighbour's slot in
+                    # front, and the pending requests of the exchange: the first chunk pass waits for them
                     self.__dict__["_tf_halo"] = shard.halo_finish(
                         halo, self.kf_attn_output.reshape(batch_size, sequence_length, dim).contiguous(), wait=False)
                 if self.use_ada_layer_norm_zero:

@@ -298,9 +298,12 @@ def gather_blend(kf_out: torch.Tensor, idx: torch.Tensor, w: Optional[torch.Tens
 
 
 def layer_norm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], eps: float,
-               out_dtype: torch.dtype, want_inv_norm: bool = False):
+               out_dtype: torch.dtype, want_inv_norm: bool = False, out: Optional[torch.Tensor] = None,
+               inv_out: Optional[torch.Tensor] = None):
     """LayerNorm over the last dim of x [..., D] (fp32 statistics, one rounding to out_dtype) and, on request,
-    1/||row||_2 of the rounded output rows (fp32 [...]).  Returns (out, inv_norm or None)."""
+    1/||row||_2 of the rounded output rows (fp32 [...]).  Returns (out, inv_norm or None).
+    out / inv_out: contiguous destination tensors of x's shape (out_dtype) / x.shape[:-1] (fp32) to write into -- e.g.
+    views of a block's halo-extended propagation state (the sharded hook pass: no staging copy behind the norm)."""
     dev = _need_gpu(x, weight, bias)
     lib = _lib.load()
     x = x.contiguous()
@@ -313,8 +316,19 @@ def layer_norm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[t
         raise TypeError(f"layer_norm: weight dtype {wt.dtype}")
     weight = weight.contiguous() if weight is not None else None
     bias = bias.contiguous() if bias is not None else None
-    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
-    inv = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device) if want_inv_norm else None
+    if out is None:
+        out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    elif out.shape != x.shape or out.dtype != out_dtype or not out.is_contiguous() or out.device != x.device:
+        raise ValueError("layer_norm: `out` must be a contiguous tensor of x's shape, out_dtype and device")
+    inv = None
+    if want_inv_norm:
+        if inv_out is None:
+            inv = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+        elif (inv_out.shape != x.shape[:-1] or inv_out.dtype != torch.float32 or not inv_out.is_contiguous()
+              or inv_out.device != x.device):
+            raise ValueError("layer_norm: `inv_out` must be a contiguous fp32 tensor of shape x.shape[:-1]")
+        else:
+            inv = inv_out
     _launch(dev, "tf_layer_norm", lib.tf_layer_norm, x.data_ptr(), weight.data_ptr() if weight is not None else 0,
             bias.data_ptr() if bias is not None else 0, out.data_ptr(), inv.data_ptr() if inv is not None else 0,
             rows, D, float(eps), _DT[x.dtype], _DT[wt.dtype] if wt is not None else 0, _DT[out_dtype])

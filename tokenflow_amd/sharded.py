@@ -73,9 +73,11 @@ class _EventRing:
     half of a rank's host time per block, profiles/r03_rank_step_v1.txt); recording an existing one costs ~1 us.  A
     wait captures the record that is current when it is issued, so an event may be re-recorded while earlier waits on
     it are still queued; a handle that is waited on only after its event has been re-recorded (the ring wrapped)
-    waits for that LATER point of the same in-order stream -- still correct, never early.  256 events cover more than
-    two passes over the 16 blocks (<= 6 per block), longer than any handle lives (a halo is waited for in the
-    propagation pass that follows its pivotal pass)."""
+    waits for that LATER point of the same in-order stream -- still correct, never early.  That argument needs every
+    event of a ring to be recorded on ONE stream: there is one ring per recording stream (the compute stream's "start"
+    events, each side stream's "done" events), never a shared one.  256 events cover more than two passes over the 16
+    blocks (<= 6 per block), longer than any handle lives (a halo is waited for in the propagation pass that follows
+    its pivotal pass)."""
 
     def __init__(self, n: int = 256):
         self._ev = [torch.cuda.Event() for _ in range(n)]
@@ -178,19 +180,21 @@ class FrameShard:
         cur = torch.cuda.current_stream(dev)
         if getattr(self, "_cs", None) is None:
             self._cs = torch.cuda.Stream(device=dev)
-            self._ring = _EventRing()
-        side = self._cs
+            self._ring = _EventRing()          # "start" events: recorded on the compute stream only
+            self._cs_done = _EventRing()       # "done" events of the exchange stream
+        side, done_ring = self._cs, self._cs_done
         if halo and getattr(self, "halo_comm", None) is not None:
             if getattr(self, "_hs", None) is None:
                 self._hs = torch.cuda.Stream(device=dev)
-            side = self._hs
+                self._hs_done = _EventRing()   # "done" events of the halo stream
+            side, done_ring = self._hs, self._hs_done
         e = self._ring.next()
         e.record(cur)
         side.wait_event(e)
         fn(side.cuda_stream)
         for t in tensors:
             t.record_stream(side)              # allocator: not reusable before the exchange stream is done with it
-        done = self._ring.next()
+        done = done_ring.next()
         done.record(side)
         return _StreamWork(done, dev)
 
@@ -200,14 +204,15 @@ class FrameShard:
         cur = torch.cuda.current_stream(dev)
         if getattr(self, "_aux", None) is None:
             self._aux = torch.cuda.Stream(device=dev)
-            self._aux_ring = _EventRing(64)
+            self._aux_ring = _EventRing(64)    # recorded on the compute stream
+            self._aux_done = _EventRing(64)    # recorded on the auxiliary stream
         e = self._aux_ring.next()
         e.record(cur)
         self._aux.wait_event(e)
         fn(self._aux.cuda_stream)
         for t in tensors:
             t.record_stream(self._aux)
-        done = self._aux_ring.next()
+        done = self._aux_done.next()
         done.record(self._aux)
         return _StreamWork(done, dev)
 
@@ -423,6 +428,16 @@ class FrameShard:
             reqs = self._p2p([piv[-1], inv[-1], kfo[0, -1], kfo[1, -1], kfo[2, -1]],
                              [piv[0], inv[0], kfo[0, 0], kfo[1, 0], kfo[2, 0]])
         return piv, inv, kfo.view(3 * (Kl + o), S, D), reqs
+
+    def halo_block(self, piv_ext: torch.Tensor, inv_ext: torch.Tensor, kfo_ext: torch.Tensor):
+        """ONE grouped neighbour exchange on halo-extended per-block state the producers have written in place
+        (`ext_alloc` layout: slot 0 = the left neighbour's last keyframe): the last local keyframe's pivots, inverse
+        norms and attention output go to rank r+1, the neighbour's arrive in slot 0.  Returns the pending requests
+        (`halo_wait`).  What `pivotal_block` issues behind its attention; the hook path calls it behind `to_out`."""
+        if self.world == 1:
+            return []
+        return self._p2p([piv_ext[-1], inv_ext[-1], kfo_ext[0, -1], kfo_ext[1, -1], kfo_ext[2, -1]],
+                         [piv_ext[0], inv_ext[0], kfo_ext[0, 0], kfo_ext[1, 0], kfo_ext[2, 0]])
 
     # ------------------------------------------------------------------ halo for propagation
     def exchange_halo(self, pivots_local: torch.Tensor, inv_local: torch.Tensor, kf_out_local: torch.Tensor):

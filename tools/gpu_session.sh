@@ -36,7 +36,9 @@ for stage in "$@"; do
     cfg1trace)  rm -rf /tmp/kt1; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt1 -- python $GRAFT_REPO_ROOT/bench.py --config cfg1 --no-cpu-baseline --no-parity --no-yardstick --steps 40 --warmup 5 > /dev/null 2>&1 )
                 python tools/rocpd_stats.py $(find /tmp/kt1 -name "*_results.db" | head -1) > $O/cfg1_kernel_stats.csv; head -30 $O/cfg1_kernel_stats.csv | cut -c1-190 ;;
     othercfgs)  for cfg in cfg4 cfg5; do timeout 600 python bench.py --config $cfg --no-cpu-baseline --no-yardstick --steps 3 --warmup 1 > $O/bench_$cfg.json 2>$O/bench_$cfg.err; python -c "import json;d=json.load(open('$O/bench_$cfg.json'));print('$cfg',d['ms_per_step'],d['parity']['attn_linf'],d['parity']['attn_linf_fp32_out'],d['parity']['nn_mismatch_rate'])"; done ;;
-    hooks)      for a in "" "--graph" "--graph --all-chunks"; do timeout 600 python tools/hooks_bench.py cfg2 6 $a >> $O/hooks_bench.txt 2>/dev/null; done; cat $O/hooks_bench.txt ;;
+    hooks)      for a in "" "--graph" "--graph --all-chunks"; do timeout 600 python tools/hooks_bench.py cfg2 6 $a >> $O/hooks_bench.txt 2>/dev/null; done
+                for a in "--ranks 8" "--ranks 8 --wire-less"; do timeout 600 python tools/hooks_bench.py cfg2 10 $a >> $O/hooks_bench.txt 2>>$O/hooks_bench.err; done; cat $O/hooks_bench.txt ;;
+    hooktests)  timeout 1500 python -m pytest tests/test_baseline_configs_gpu.py -q --tb=short -p no:cacheprovider -x -k "hooks" 2>&1 | tail -15 ;;
     gloo8)      timeout 900 python bench.py --gpus 8 --backend gloo --steps 2 --warmup 1 > $O/bench_gloo8.txt 2>&1; tail -c 1500 $O/bench_gloo8.txt ;;
     *) echo "unknown stage $stage" ;;
   esac

@@ -9,6 +9,11 @@ calls the ops directly on pre-made tensors.
       --proj        keep attn1's q/k/v/out Linear layers (default: identities)
       --graph       replay every pass from a HIP graph (tokenflow_amd.graphs.GraphCache): one host call per pass
       --all-chunks  ONE propagation pass over all chunks (register_batch_idx(model, range(K))) instead of K passes
+      --ranks W [--rank r] [--wire-less]
+                    ONE rank of a W-GPU frame-sharded run through the hook API (register_frame_shard with a NativeShard on
+                    the library's loopback transport: every exchange a same-size local copy; --wire-less: no copies at
+                    all): the rank's Kl keyframes in the pivotal pass, its own chunks in the chunk passes.  Compare with
+                    tools/rank_step_microbench.py --native (the same rank through bench.py's direct op calls).
 """
 import os
 import sys
@@ -51,7 +56,18 @@ GRAPH = "--graph" in sys.argv
 ALL_CHUNKS = "--all-chunks" in sys.argv
 
 
+def _opt(name, default):
+    if name in sys.argv:
+        i = sys.argv.index(name)
+        v = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
+        return int(v)
+    return default
+
+
 def main():
+    ranks, rank = _opt("--ranks", 1), _opt("--rank", 1)
+    wireless = "--wire-less" in sys.argv
     argv = [a for a in sys.argv[1:] if not a.startswith("--")]
     cfg = workload.CONFIGS[argv[0] if len(argv) > 0 else "cfg2"]
     steps = int(argv[1]) if len(argv) > 1 else 6
@@ -64,14 +80,22 @@ def main():
         blk.attn1.t = 5
     tfu.set_tokenflow(holder)
     K, n = cfg.K, cfg.chunk
+    shard, Kq, chunks = None, K, list(range(K))
+    if ranks > 1:
+        from tokenflow_amd import sharded
+        from tokenflow_amd.comm import HipComm
+        shard = sharded.NativeShard(K, HipComm.loopback(rank, ranks, copies=not wireless),
+                                    HipComm.loopback(rank, ranks, copies=not wireless), attn_split="--one-pass" not in sys.argv)
+        hooks.register_frame_shard(holder, shard)
+        Kq, chunks = shard.Kl, list(range(shard.kf0, shard.kf0 + shard.Kl))
     g = torch.Generator(device=dev).manual_seed(0)
-    xs_piv = [torch.randn(3 * K, cfg.levels[l][0], cfg.levels[l][1], generator=g, device=dev, dtype=dtype)
+    xs_piv = [torch.randn(3 * Kq, cfg.levels[l][0], cfg.levels[l][1], generator=g, device=dev, dtype=dtype)
               for _, l, _ in blocks]
     xs_chk = [torch.randn(3 * n, cfg.levels[l][0], cfg.levels[l][1], generator=g, device=dev, dtype=dtype)
               for _, l, _ in blocks]
 
     if ALL_CHUNKS:     # one pass carries every chunk: frames chunk-major inside each branch
-        xs_chk = [x.view(3, 1, n, *x.shape[1:]).expand(3, K, n, *x.shape[1:]).reshape(3 * K * n, *x.shape[1:]).contiguous()
+        xs_chk = [x.view(3, 1, n, *x.shape[1:]).expand(3, len(chunks), n, *x.shape[1:]).reshape(3 * len(chunks) * n, *x.shape[1:]).contiguous()
                   for x in xs_chk]
     cache = None
     if GRAPH:
@@ -84,7 +108,7 @@ def main():
 
     def chunk_pass(c, *xs):
         tfu.register_pivotal(holder, False)
-        tfu.register_batch_idx(holder, range(K) if ALL_CHUNKS else c)
+        tfu.register_batch_idx(holder, range(chunks[0], chunks[-1] + 1) if ALL_CHUNKS else c)
         return [blk(x) for (blk, _, _), x in zip(blocks, xs)]
 
     def step(inject_on):
@@ -102,11 +126,11 @@ def main():
                     except KeyError:
                         return default
                 cache.run(("pivotal", inject_on), pivotal_pass, *feed(("pivotal", inject_on), xs_piv))
-                for c in ([0] if ALL_CHUNKS else range(K)):
+                for c in ([chunks[0]] if ALL_CHUNKS else chunks):
                     cache.run(("chunk", c), lambda *xs, c=c: chunk_pass(c, *xs), *feed(("chunk", c), xs_chk))
             else:
                 pivotal_pass(*xs_piv)
-                for c in ([0] if ALL_CHUNKS else range(K)):
+                for c in ([chunks[0]] if ALL_CHUNKS else chunks):
                     chunk_pass(c, *xs_chk)
 
     for i in range(2):
@@ -119,6 +143,8 @@ def main():
     torch.cuda.synchronize()
     t = time.perf_counter() - t0
     mode = ("graph replay" if GRAPH else "eager") + (", one pass over all chunks" if ALL_CHUNKS else "") + (", real projections" if PROJ else "")
+    if shard is not None:
+        mode += f", rank {rank} of {ranks} (native executor, loopback transport{' without copies' if wireless else ''})"
     print(f"hooks path [{mode}], {cfg.name}: {t / steps * 1e3:.2f} ms/step ({cfg.frames * steps / t:.0f} frames/s); "
           f"host-side issue time {t_cpu / steps * 1e3:.2f} ms/step")
 
