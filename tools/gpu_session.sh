@@ -38,7 +38,7 @@ for stage in "$@"; do
     othercfgs)  for cfg in cfg4 cfg5; do timeout 600 python bench.py --config $cfg --no-cpu-baseline --no-yardstick --steps 3 --warmup 1 > $O/bench_$cfg.json 2>$O/bench_$cfg.err; python -c "import json;d=json.load(open('$O/bench_$cfg.json'));print('$cfg',d['ms_per_step'],d['parity']['attn_linf'],d['parity']['attn_linf_fp32_out'],d['parity']['nn_mismatch_rate'])"; done ;;
     hooks)      for a in "" "--graph" "--graph --all-chunks"; do timeout 600 python tools/hooks_bench.py cfg2 6 $a >> $O/hooks_bench.txt 2>/dev/null; done
                 for a in "--ranks 8" "--ranks 8 --wire-less"; do timeout 600 python tools/hooks_bench.py cfg2 10 $a >> $O/hooks_bench.txt 2>>$O/hooks_bench.err; done; cat $O/hooks_bench.txt ;;
-    hooktests)  timeout 1500 python -m pytest tests/test_baseline_configs_gpu.py -q --tb=short -p no:cacheprovider -x -k "hooks" 2>&1 | tail -15 ;;
+    hooktests)  timeout 1500 python -m pytest tests/test_baseline_configs_gpu.py tests/test_sharded_gpu.py -q --tb=short -p no:cacheprovider -x -k "hooks or hipgraph or cfg1" 2>&1 | tail -15 ;;
     gloo8)      timeout 900 python bench.py --gpus 8 --backend gloo --steps 2 --warmup 1 > $O/bench_gloo8.txt 2>&1; tail -c 1500 $O/bench_gloo8.txt ;;
     *) echo "unknown stage $stage" ;;
   esac
