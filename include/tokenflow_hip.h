@@ -54,6 +54,7 @@ extern "C" {
 /* tuning hints of the fused small-problem kernel (0 = automatic; A/B measurements, tools/attn_microbench.py) */
 #define TF_ATTN_HINT_QW(code) (((code) & 7) << 8)    /* code 1, 2, 3 = 1 (the wave-private form), 2, 4 query waves per workgroup */
 #define TF_ATTN_HINT_KW(code) (((code) & 7) << 11)   /* code 1, 2, 3, 4 = 1, 2, 4, 8 key groups per workgroup */
+#define TF_ATTN_HINT_QB2 (1 << 14)                   /* wave-private form, head dims <= 80: two 32-query blocks per wave */
 #define TF_ATTN_PRECISE_P (1 << 15)                  /* fused kernel, bf16: carry P as hi + lo whatever the size */
 #define TF_ATTN_NO_PRECISE_P (1 << 16)               /* fused kernel: P in one 16-bit value whatever the size */
 

@@ -47,6 +47,9 @@ def test_fused_geometries_vs_oracle(K, S, h, d, geom, inject):
     for prec in (lib.TF_ATTN_NO_PRECISE_P, lib.TF_ATTN_PRECISE_P):
         out = ops.ext_attn(dq, dk, dv, h, d ** -0.5, inject, fused=True, hints=lib.attn_hint(*geom) | prec)
         assert_attn_close(out, refs, f"fused K{K} S{S} h{h} d{d} geom{geom} inj{inject} prec{prec != lib.TF_ATTN_NO_PRECISE_P}")
+        if geom == (1, 4) and d <= 80:     # two query blocks per wave: the same bits (the arithmetic of a query is unchanged)
+            two = ops.ext_attn(dq, dk, dv, h, d ** -0.5, inject, fused=True, hints=lib.attn_hint(1, 4, qb=2) | prec)
+            assert torch.equal(two, out), f"two query blocks per wave differ: K{K} S{S} h{h} d{d}"
 
 
 @pytest.mark.parametrize("K,S,h,d", [(8, 1024, 1, 80), (4, 1024, 2, 40), (2, 576, 2, 64), (3, 320, 1, 160)])
@@ -62,6 +65,10 @@ def test_fused_long_sequences(K, S, h, d, dtype):
         out = ops.ext_attn(dq, dk, dv, h, d ** -0.5, inject, fused=True)
         assert out.dtype == dtype
         assert_attn_close(out, refs, f"fused long K{K} S{S} h{h} d{d} {dtype} inj{inject}", dtype=dtype)
+        if d <= 80:
+            two = ops.ext_attn(dq, dk, dv, h, d ** -0.5, inject, fused=True, hints=lib.attn_hint(1, 4, qb=2))
+            assert_attn_close(two, refs, f"fused long, two query blocks per wave K{K} S{S} h{h} d{d} {dtype}", dtype=dtype)
+            assert torch.equal(two, ops.ext_attn(dq, dk, dv, h, d ** -0.5, inject, fused=True, hints=lib.attn_hint(1, 4)))
 
 
 @pytest.mark.parametrize("K,S,h,d", [(8, 64, 8, 160), (8, 256, 2, 160), (4, 16, 8, 160), (4, 64, 8, 160), (4, 256, 4, 80),

@@ -11,14 +11,14 @@ TF_ATTN_INJECT, TF_ATTN_EXACT_SCALE, TF_ATTN_BANK_ONLY, TF_ATTN_SOURCE_ONLY, TF_
 TF_ATTN_OUT_F32 = 32
 TF_ATTN_FOLD_SCALE = 64
 TF_ATTN_NO_FUSED, TF_ATTN_FUSED = 128, 1 << 17
-TF_ATTN_PRECISE_P, TF_ATTN_NO_PRECISE_P = 1 << 15, 1 << 16
+TF_ATTN_HINT_QB2, TF_ATTN_PRECISE_P, TF_ATTN_NO_PRECISE_P = 1 << 14, 1 << 15, 1 << 16
 
 
-def attn_hint(qw: int = 0, kw: int = 0) -> int:
+def attn_hint(qw: int = 0, kw: int = 0, qb: int = 1) -> int:
     """TF_ATTN_HINT_QW / _KW bits of the fused small-problem kernel: qw in {0 (auto), 1 (the wave-private form), 2, 4}
     query waves per workgroup, kw in {0 (auto), 1, 2, 4, 8} key groups."""
     code = {0: 0, 1: 1, 2: 2, 4: 3, 8: 4}
-    return (code[qw] << 8) | (code[kw] << 11)
+    return (code[qw] << 8) | (code[kw] << 11) | (TF_ATTN_HINT_QB2 if qb == 2 else 0)
 
 
 ABI_VERSION = 5

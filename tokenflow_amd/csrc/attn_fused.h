@@ -26,6 +26,7 @@ struct TfFusedPlan {
     int use;    // take the fused kernel
     int qw;     // query waves per workgroup (32 queries each; they share every staged key tile); 1 = the wave-private form
     int kw;     // key groups per workgroup (the in-workgroup split of the key sequence, merged through LDS)
+    int qb;     // 32-query blocks per wave (wave-private form: 2 = every K / V^T fragment feeds two MFMAs)
     int prec;   // P carried as hi + lo bf16 (two P.V MFMAs): removes the rounding of P from the result
 };
 

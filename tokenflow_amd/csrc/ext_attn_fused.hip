@@ -144,14 +144,14 @@ struct Cursor {
     }
 };
 
-// online softmax of one 32-key sub-tile (lane-local; the two lanes of a query share the maximum) and O^T += V^T P
-// with the V^T fragments transpose-read from the row-major V image `vtr` (this lane's address for k-step 0, M-tile 0)
+// online softmax of one 32-key sub-tile (lane-local; the two lanes of a query share the maximum): rescales O when the
+// running maximum of some query of the wave moved, leaves P of the two 16-key k-steps (registers 0-7 / 8-15 of the
+// accumulator) in ph (and the rounding remainders in pl with PREC)
 template <typename T, int DH, bool PREC>
-__device__ __forceinline__ void softmax_pv(f32x16& s, f32x16 (&o)[FusedCfg<DH>::MT], float& m_run, float& l_run, float c,
-                                           const typename T::elem* vtr) {
+__device__ __forceinline__ void softmax_p(f32x16& s, f32x16 (&o)[FusedCfg<DH>::MT], float& m_run, float& l_run, float c,
+                                          typename T::vec8 (&ph)[2], typename T::vec8 (&pl)[2]) {
     typedef FusedCfg<DH> C;
     typedef typename T::elem E;
-    typedef typename T::vec8 vec8;
     float mx = s[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
@@ -167,7 +167,6 @@ __device__ __forceinline__ void softmax_pv(f32x16& s, f32x16 (&o)[FusedCfg<DH>::
             for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
     }
     const float mc = m_run * c;
-    vec8 ph[2], pl[2];   // P of the two 16-key k-steps: registers 0-7 / 8-15 of the accumulator
     float lsum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -178,6 +177,15 @@ __device__ __forceinline__ void softmax_pv(f32x16& s, f32x16 (&o)[FusedCfg<DH>::
         if constexpr (PREC) pl[r >> 3][r & 7] = (E)(pr - (float)e);
     }
     l_run += lsum;
+}
+
+// O^T += V^T P for the QB query blocks of a wave: every V^T fragment is transpose-read ONCE from the row-major V image
+// `vtr` (this lane's address for k-step 0, M-tile 0) and multiplied into each block's accumulator
+template <typename T, int DH, int QB, bool PREC>
+__device__ __forceinline__ void pv_acc(f32x16 (&o)[QB][FusedCfg<DH>::MT], typename T::vec8 (&ph)[QB][2],
+                                       typename T::vec8 (&pl)[QB][2], const typename T::elem* vtr) {
+    typedef FusedCfg<DH> C;
+    typedef typename T::vec8 vec8;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -185,8 +193,11 @@ __device__ __forceinline__ void softmax_pv(f32x16& s, f32x16 (&o)[FusedCfg<DH>::
             const u32x2 a0 = TrRead<T>::rd(vtr + (16 * ks) * C::VS + mt * 32);
             const u32x2 a1 = TrRead<T>::rd(vtr + (16 * ks + 8) * C::VS + mt * 32);
             const vec8 a = __builtin_bit_cast(vec8, u32x4{a0[0], a0[1], a1[0], a1[1]});
-            o[mt] = T::mfma32(a, ph[ks], o[mt]);
-            if constexpr (PREC) o[mt] = T::mfma32(a, pl[ks], o[mt]);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                o[qb][mt] = T::mfma32(a, ph[qb][ks], o[qb][mt]);
+                if constexpr (PREC) o[qb][mt] = T::mfma32(a, pl[qb][ks], o[qb][mt]);
+            }
         }
 }
 
@@ -350,13 +361,13 @@ __global__ __launch_bounds__(64 * QW * KW, 1) void ext_attn_fused_kernel(FusedPa
             }
     };
 
-    f32x16 o[C::MT];
+    f32x16 o[1][C::MT];
     float m_run = -INFINITY;   // running maximum of the raw scores of this wave's sub-tiles
     float l_run = 0.f;         // this lane's share of the denominator
 #pragma unroll
     for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[mt][r] = 0.f;
+        for (int r = 0; r < 16; ++r) o[0][mt][r] = 0.f;
     const float c = p.c;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
@@ -385,33 +396,39 @@ __global__ __launch_bounds__(64 * QW * KW, 1) void ext_attn_fused_kernel(FusedPa
                 for (int r = 0; r < 16; ++r)
                     if (key0 + cd_row(r, hi) >= S) s[r] = -INFINITY;
             }
-            softmax_pv<T, DH, PREC>(s, o, m_run, l_run, c, vtr);
+            vec8 ph[1][2], pl[1][2];
+            softmax_p<T, DH, PREC>(s, o[0], m_run, l_run, c, ph[0], pl[0]);
+            pv_acc<T, DH, 1, PREC>(o, ph, pl, vtr);
             cc.advance(KW, tpf, nst);
         }
         __syncthreads();   // every wave is done with this iteration's sub-tiles
     }
     const int64_t out_row = pr.b * st.o_bs + pr.f * st.o_fs + (int64_t)q_row * (st.H * DH) + pr.h * DH;
-    merge_store<T, DH, QW, KW>(smem, o, m_run, l_run, c, wave, lane, st.out, out_row, q_ok, p.out_f32);
+    merge_store<T, DH, QW, KW>(smem, o[0], m_run, l_run, c, wave, lane, st.out, out_row, q_ok, p.out_f32);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Wave-private form (small grids: a sharded rank's share of a level, BASELINE config 1): ONE 32-query tile per workgroup,
-// its key sequence split over KW = 4 or 8 waves, and NOTHING shared between the waves until the merge -- so the main
-// loop has no workgroup barrier at all: every wave streams its own sub-tiles at its own pace.
+// Wave-private form (small grids: a sharded rank's share of a level, BASELINE config 1): ONE tile of 32*QB queries per
+// workgroup, its key sequence split over KW = 4 or 8 waves, and NOTHING shared between the waves until the merge -- so
+// the main loop has no workgroup barrier at all: every wave streams its own sub-tiles at its own pace.
 //   * K: the MFMA A fragments (a key row per lane, 16 B per k-step) are loaded straight from global memory into
 //     registers, one sub-tile ahead (these problems are L2-resident; LDS would buy coalescing only);
 //   * V: loaded one sub-tile ahead (lane = half a key row), written row-major into the wave's private LDS region and
 //     transpose-read as V^T fragments.  LDS operations of one wave execute in order, so write -> read -> next write
 //     need no barrier;
-//   * Q: registers; at Dh = 160 (where the accumulators alone are 80 registers) in LDS, shared by the KW waves.
+//   * Q: registers; at Dh = 160 (where the accumulators alone are 80 registers) in LDS, shared by the KW waves;
+//   * QB = 2 (head dims <= 80, longer key sequences): a wave owns two 32-query blocks -- every K and V^T fragment it
+//     fetches feeds two MFMAs, which halves the K / V re-reads per query (a wave-private problem is bound by the L1's
+//     64 B/clk once thousands of keys stream through every 32-query tile).
 // Same arithmetic per (query, head) as the shared-tile form with the same KW: bit-identical results.
-template <typename T, int DH, int KW, bool PREC>
+template <typename T, int DH, int KW, int QB, bool PREC>
 __global__ __launch_bounds__(64 * KW, 1) void ext_attn_fused_wp_kernel(FusedParams p) {
     typedef FusedCfg<DH> C;
     typedef typename T::elem E;
     typedef typename T::vec8 vec8;
     constexpr int NT = 64 * KW;
     constexpr bool LQ = DH == 160;                    // Q fragments from LDS
+    static_assert(!(LQ && QB > 1), "two query blocks per wave: head dims <= 80");
     constexpr int NPH = (C::PPR + 1) / 2;             // 16-B pieces of V per lane and sub-tile (half a row)
     constexpr int V_ELEMS = 32 * C::VS;
     constexpr int STAGE_BYTES = (KW * V_ELEMS + (LQ ? C::K_ELEMS : 0)) * 2;
@@ -437,25 +454,32 @@ __global__ __launch_bounds__(64 * KW, 1) void ext_attn_fused_wp_kernel(FusedPara
     const int ld = (int)st.ld;
 
     // ---- Q fragments
-    const int q_row = pr.qt * 32 + l31;
-    const bool q_ok = q_row < S;
-    const E* qp = reinterpret_cast<const E*>(st.q) + pr.bq * st.q_bs + pr.f * st.q_fs +
-                  (int64_t)(q_ok ? q_row : S - 1) * st.ld_q + pr.h * DH;
-    vec8 qf[LQ ? 1 : C::KS];
+    int q_row[QB];
+    bool q_ok[QB];
+    vec8 qf[QB][LQ ? 1 : C::KS];
+    const E* qbase = reinterpret_cast<const E*>(st.q) + pr.bq * st.q_bs + pr.f * st.q_fs + pr.h * DH;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        q_row[qb] = (pr.qt * QB + qb) * 32 + l31;
+        q_ok[qb] = q_row[qb] < S;
+    }
     if constexpr (LQ) {
         // the 32 x DH query tile, row-major with the K image's row stride: every wave copies 32 / KW rows
         for (int id = tid; id < 32 * C::PPR; id += NT) {
             const int row = id / C::PPR, pc = id - row * C::PPR;
             const int qr = min(pr.qt * 32 + row, S - 1);
-            st16(sQ + row * C::KROW + pc * 8,
-                 ld16(reinterpret_cast<const E*>(st.q) + pr.bq * st.q_bs + pr.f * st.q_fs + (int64_t)qr * st.ld_q + pr.h * DH + pc * 8));
+            st16(sQ + row * C::KROW + pc * 8, ld16(qbase + (int64_t)qr * st.ld_q + pc * 8));
         }
         __syncthreads();
     } else {
 #pragma unroll
-        for (int t = 0; t < C::KS; ++t) {
-            const int col = 16 * t + 8 * hi;
-            qf[t] = __builtin_bit_cast(vec8, col < DH ? ld16(qp + col) : u32x4{0, 0, 0, 0});
+        for (int qb = 0; qb < QB; ++qb) {
+            const E* qp = qbase + (int64_t)(q_ok[qb] ? q_row[qb] : S - 1) * st.ld_q;
+#pragma unroll
+            for (int t = 0; t < C::KS; ++t) {
+                const int col = 16 * t + 8 * hi;
+                qf[qb][t] = __builtin_bit_cast(vec8, col < DH ? ld16(qp + col) : u32x4{0, 0, 0, 0});
+            }
         }
     }
     const E* qfrag = sQ + l31 * C::KROW + 8 * hi;
@@ -478,12 +502,16 @@ __global__ __launch_bounds__(64 * KW, 1) void ext_attn_fused_wp_kernel(FusedPara
         ldc.advance(KW, tpf, nst);
     };
 
-    f32x16 o[C::MT];
-    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 o[QB][C::MT];
+    float m_run[QB], l_run[QB];
 #pragma unroll
-    for (int mt = 0; mt < C::MT; ++mt)
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = -INFINITY, l_run[qb] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[mt][r] = 0.f;
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][mt][r] = 0.f;
+    }
     const float c = p.c;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int li = lane & 15, lg = lane >> 4;
@@ -498,25 +526,37 @@ __global__ __launch_bounds__(64 * KW, 1) void ext_attn_fused_wp_kernel(FusedPara
         for (int j2 = 0; j2 < NPH; ++j2)
             if (v_pc0 + j2 < C::PPR) st16(sV + v_row * C::VS + (v_pc0 + j2) * 8, rv[j2]);
         __builtin_amdgcn_wave_barrier();
-        // S^T = K Q^T from the register-resident K fragments
-        f32x16 s = zero;
+        // S^T = K Q^T from the register-resident K fragments (k-step outermost: consecutive MFMAs hit different accumulators)
+        f32x16 s[QB];
 #pragma unroll
-        for (int t = 0; t < C::KS; ++t) {
-            const vec8 qv = LQ ? __builtin_bit_cast(vec8, ld16(qfrag + 16 * t)) : qf[LQ ? 0 : t];
-            s = T::mfma32(__builtin_bit_cast(vec8, rk[t]), qv, s);
-        }
+        for (int qb = 0; qb < QB; ++qb) s[qb] = zero;
+#pragma unroll
+        for (int t = 0; t < C::KS; ++t)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const vec8 qv = LQ ? __builtin_bit_cast(vec8, ld16(qfrag + 16 * t)) : qf[qb][LQ ? 0 : t];
+                s[qb] = T::mfma32(__builtin_bit_cast(vec8, rk[t]), qv, s[qb]);
+            }
         load_tile();   // K(i+1), V(i+1) fly under the softmax and the P.V MFMAs (past the end: a harmless re-load)
-        if (key0 + 32 > S) {
+        vec8 ph[QB][2], pl[QB][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (key0 + cd_row(r, hi) >= S) s[r] = -INFINITY;
+        for (int qb = 0; qb < QB; ++qb) {
+            if (key0 + 32 > S) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key0 + cd_row(r, hi) >= S) s[qb][r] = -INFINITY;
+            }
+            softmax_p<T, DH, PREC>(s[qb], o[qb], m_run[qb], l_run[qb], c, ph[qb], pl[qb]);
         }
-        softmax_pv<T, DH, PREC>(s, o, m_run, l_run, c, vtr);
+        pv_acc<T, DH, QB, PREC>(o, ph, pl, vtr);
         __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();   // every wave has left its loop: the staging area becomes the merge area
-    const int64_t out_row = pr.b * st.o_bs + pr.f * st.o_fs + (int64_t)q_row * (st.H * DH) + pr.h * DH;
-    merge_store<T, DH, 1, KW>(smem, o, m_run, l_run, c, kw, lane, st.out, out_row, q_ok, p.out_f32);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        __syncthreads();   // every wave has left its loop (or the previous block's merge): the LDS becomes the merge area
+        const int64_t out_row = pr.b * st.o_bs + pr.f * st.o_fs + (int64_t)q_row[qb] * (st.H * DH) + pr.h * DH;
+        merge_store<T, DH, 1, KW>(smem, o[qb], m_run[qb], l_run[qb], c, kw, lane, st.out, out_row, q_ok[qb], p.out_f32);
+    }
 }
 
 template <typename T, int DH, int QW, int KW, bool PREC>
@@ -532,12 +572,12 @@ int launch_fused(const FusedParams& p, unsigned grid, hipStream_t st) {
     return 0;
 }
 
-template <typename T, int DH, int KW, bool PREC>
+template <typename T, int DH, int KW, int QB, bool PREC>
 int launch_fused_wp(const FusedParams& p, unsigned grid, hipStream_t st) {
     typedef FusedCfg<DH> C;
     constexpr int STAGE_BYTES = (KW * 32 * C::VS + (DH == 160 ? C::K_ELEMS : 0)) * 2;
     constexpr int lds = STAGE_BYTES > merge_bytes<KW, KW>() ? STAGE_BYTES : merge_bytes<KW, KW>();
-    auto kern = ext_attn_fused_wp_kernel<T, DH, KW, PREC>;
+    auto kern = ext_attn_fused_wp_kernel<T, DH, KW, QB, PREC>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * KW), lds, st, p);
     TF_LAUNCH_CHECK("tf_ext_attn_fwd(fused)");
@@ -545,9 +585,17 @@ int launch_fused_wp(const FusedParams& p, unsigned grid, hipStream_t st) {
 }
 
 template <typename T, int DH, bool PREC>
-int dispatch_geom(const FusedParams& p, unsigned grid, int qw, int kw, hipStream_t st) {
-    if (qw == 1 && kw == 4) return launch_fused_wp<T, DH, 4, PREC>(p, grid, st);
-    if (qw == 1 && kw == 8) return launch_fused_wp<T, DH, 8, PREC>(p, grid, st);
+int dispatch_geom(const FusedParams& p, unsigned grid, int qw, int kw, int qb, hipStream_t st) {
+    if constexpr (DH <= 80) {
+        if (qw == 1 && kw == 4 && qb == 2) return launch_fused_wp<T, DH, 4, 2, PREC>(p, grid, st);
+    }
+    if (qw == 1 && kw == 4 && qb == 1) return launch_fused_wp<T, DH, 4, 1, PREC>(p, grid, st);
+    if (qw == 1 && kw == 8 && qb == 1) return launch_fused_wp<T, DH, 8, 1, PREC>(p, grid, st);
+    if (qb != 1) {
+        tf_set_error("tf_ext_attn_fwd(fused): two query blocks per wave exist for the wave-private form with 4 key groups, "
+                     "head dims <= 80");
+        return TF_ERR_SHAPE;
+    }
     if (qw == 2 && kw == 4) return launch_fused<T, DH, 2, 4, PREC>(p, grid, st);
     if (qw == 4 && kw == 2) return launch_fused<T, DH, 4, 2, PREC>(p, grid, st);
     if (qw == 4 && kw == 1) return launch_fused<T, DH, 4, 1, PREC>(p, grid, st);
@@ -558,8 +606,8 @@ int dispatch_geom(const FusedParams& p, unsigned grid, int qw, int kw, hipStream
 template <typename T, int DH>
 int dispatch_prec(const FusedParams& p, unsigned grid, const TfFusedPlan& plan, hipStream_t st) {
     constexpr bool bf = std::is_same<T, BF16>::value;
-    if (bf && plan.prec) return dispatch_geom<T, DH, bf>(p, grid, plan.qw, plan.kw, st);
-    return dispatch_geom<T, DH, false>(p, grid, plan.qw, plan.kw, st);
+    if (bf && plan.prec) return dispatch_geom<T, DH, bf>(p, grid, plan.qw, plan.kw, plan.qb, st);
+    return dispatch_geom<T, DH, false>(p, grid, plan.qw, plan.kw, plan.qb, st);
 }
 
 template <typename T>
@@ -620,6 +668,7 @@ TfFusedPlan tf_attn_fused_plan(const TfAttnSet* sets, int n_sets, int S, int Dh,
         pl.kw = 4;
         pl.qw = 1;
     }
+    pl.qb = 1;
     if (flags & TF_ATTN_FUSED) pl.use = 1;
     if (!pl.use) return pl;
     pl.prec = dtype == TF_BF16 && S <= 256;
@@ -627,6 +676,7 @@ TfFusedPlan tf_attn_fused_plan(const TfAttnSet* sets, int n_sets, int S, int Dh,
     const int hq = (flags >> 8) & 7, hk = (flags >> 11) & 7;
     if (hq) pl.qw = 1 << (hq - 1);
     if (hk) pl.kw = 1 << (hk - 1);   // codes 1..4 = 1, 2, 4, 8 key groups
+    if (flags & TF_ATTN_HINT_QB2) pl.qb = 2;
     if (flags & TF_ATTN_PRECISE_P) pl.prec = dtype == TF_BF16;
     if (flags & TF_ATTN_NO_PRECISE_P) pl.prec = 0;
     return pl;
@@ -638,7 +688,7 @@ int tf_attn_fused_launch(const TfAttnSet* sets, int n_sets, int S, int Dh, float
     FusedParams p{};
     p.n_sets = n_sets;
     p.S = S;
-    p.nQT = (S + 32 * plan.qw - 1) / (32 * plan.qw);
+    p.nQT = (S + 32 * plan.qw * plan.qb - 1) / (32 * plan.qw * plan.qb);
     p.tpf = (S + 31) / 32;
     p.tpf_magic = p.tpf > 1 ? (unsigned)(((uint64_t)1 << 32) / (unsigned)p.tpf + 1) : 0u;
     p.inject = (flags & TF_ATTN_INJECT) ? 1 : 0;

@@ -84,6 +84,8 @@ def main():
             for geom in ((1, 4), (1, 8), (2, 4), (4, 2), (4, 1)):
                 t("%dx%d" % geom, fused=True, hints=_lib.attn_hint(*geom) | _lib.TF_ATTN_NO_PRECISE_P)
                 t("%dx%dp" % geom, fused=True, hints=_lib.attn_hint(*geom) | _lib.TF_ATTN_PRECISE_P)
+            if d <= 80:
+                t("1x4q2", fused=True, hints=_lib.attn_hint(1, 4, qb=2) | _lib.TF_ATTN_NO_PRECISE_P)
             print(f"{label:17s} K={K} S={S} h={h} d={d} inj={int(inj)} {fl / 1e9:7.1f} GFLOP | us avg/min: " + " | ".join(row), flush=True)
 
 
