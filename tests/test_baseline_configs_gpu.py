@@ -539,6 +539,59 @@ def test_hipgraph_replay_of_hook_passes(dtype):
     assert len(cache) == 2
 
 
+@pytest.mark.parametrize("native", [False, True])
+def test_hipgraph_replay_of_a_sharded_rank(native):
+    """The hook passes of ONE rank of a frame-sharded run (register_frame_shard on the library's loopback transport:
+    rank 3 of 8, every exchange a stream-ordered local copy) captured into HIP graphs: the pivotal pass ends with
+    hooks.join_frame_shard (a capture joins the halo stream before it ends), the chunk pass then waits for nothing.
+    Replays equal the eager passes bit for bit, for new input contents."""
+    from tokenflow_amd import sharded
+    from tokenflow_amd.comm import HipComm
+    from tokenflow_amd.graphs import GraphCache
+    dtype = torch.bfloat16
+    holder, blk = _one_block_pipe(640, 8, "cuda", dtype)
+    K, n, S = 8, 2, 256
+    comm, hcomm = HipComm.loopback(3, 8), HipComm.loopback(3, 8)
+    shard = (sharded.NativeShard(K, comm, hcomm) if native else sharded.FrameShard(K, comm=comm, halo_comm=hcomm))
+    hooks.register_frame_shard(holder, shard)
+    g = torch.Generator().manual_seed(4)
+    enc, enc_n = (torch.randn(3 * m, 7, 32, generator=g).cuda().to(dtype) for m in (shard.Kl, n))
+
+    def mk(m):
+        return torch.randn(3 * m, S, 640, generator=g).cuda().to(dtype)
+
+    def pivotal(x, join):
+        tfu.register_pivotal(holder, True)
+        y = blk(x, encoder_hidden_states=enc)
+        if join:
+            hooks.join_frame_shard(holder)
+        return y
+
+    def chunk(x):
+        tfu.register_pivotal(holder, False)
+        tfu.register_batch_idx(holder, shard.kf0)
+        return blk(x, encoder_hidden_states=enc_n)
+
+    cache = GraphCache()
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+            for rep in range(3):
+                xp, xc = mk(shard.Kl), mk(n)
+                want_p = pivotal(xp, False).clone()
+                want_c = chunk(xc).clone()                 # eager: the chunk pass waits for the halo itself
+                got_p = cache.run(("pivotal", True), lambda x: pivotal(x, True), xp).clone()
+                got_c = cache.run(("chunk", shard.kf0, True), chunk, xc).clone()
+                torch.cuda.synchronize()
+                assert torch.equal(got_p, want_p) and torch.equal(got_c, want_c), rep
+        assert len(cache) == 2
+    finally:
+        hooks.register_frame_shard(holder, None)
+        if native:
+            shard.close()
+        comm.close()
+        hcomm.close()
+
+
 # ------------------------------------------------------------------------------------------- collective-shaped layouts
 @pytest.mark.parametrize("K,S,h,d", [(4, 320, 2, 40), (3, 136, 2, 64), (2, 264, 1, 80), (2, 72, 1, 160), (5, 1024, 1, 40),
                                      (4, 4096, 8, 40)])       # the last one: the interleaved Dh = 40 kernel

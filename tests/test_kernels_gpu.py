@@ -327,7 +327,7 @@ def test_nn_search_golden_cases(name, golden_prop):
 
 
 @pytest.mark.parametrize("K,n,S,D", [(2, 3, 200, 320), (3, 2, 64, 1280), (2, 5, 16, 1280), (2, 1, 520, 640),
-                                     (2, 9, 128, 72)])
+                                     (2, 9, 128, 72), (2, 2, 200, 1280), (2, 1, 72, 1096), (3, 4, 256, 1280)])
 def test_nn_search_shapes(K, n, S, D):
     """S not a multiple of the 128-pivot tile, target count not a multiple of the panel,
     D not a multiple of the 64-wide chunk, deep D."""
@@ -483,6 +483,25 @@ def test_layer_norm_vs_torch_fp32(rows, D, in_dt, w_dt, out_dt):
     same = ops.pivot_inv_norm(out) if out_dt != torch.float32 else None
     if same is not None:          # the producer's side output and the stand-alone kernel agree
         assert torch.allclose(inv, same, rtol=2e-6, atol=0)
+
+
+def test_layer_norm_into_caller_buffers():
+    """out= / inv_out=: the kernel writes into the caller's (row-contiguous) views -- the in-place sharded hook pass
+    hands it slices of the halo-extended block state -- and returns those views; same bits as the allocating call."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(6 * 64, 320, generator=g).bfloat16().cuda()
+    w, b = (torch.randn(320, generator=g).cuda() for _ in range(2))
+    want, want_inv = ops.layer_norm(x, w, b, 1e-5, torch.bfloat16, want_inv_norm=True)
+    state = torch.zeros(8 * 64, 320, dtype=torch.bfloat16, device="cuda")
+    inv_state = torch.zeros(8 * 64, dtype=torch.float32, device="cuda")
+    out, inv = ops.layer_norm(x, w, b, 1e-5, torch.bfloat16, want_inv_norm=True, out=state[64:7 * 64],
+                              inv_out=inv_state[64:7 * 64])
+    assert out.data_ptr() == state[64:].data_ptr() and inv.data_ptr() == inv_state[64:].data_ptr()
+    assert torch.equal(state[64:7 * 64], want) and torch.equal(inv_state[64:7 * 64], want_inv)
+    assert not bool(state[:64].any()) and not bool(state[7 * 64:].any())       # nothing outside the view
+    with pytest.raises(ValueError):
+        ops.layer_norm(x, w, b, 1e-5, torch.bfloat16, out=state[:64])           # wrong shape
 
 
 def test_layer_norm_argument_errors():

@@ -422,6 +422,27 @@ def test_native_rank_executor_single_rank_and_loopback():
         comm.close()
 
 
+def test_loopback_transport_copies_switch():
+    """tf_comm_init_loopback stands in for the wire with same-size local copies; tf_comm_loopback_copies(0) leaves the
+    calls in place and moves nothing (the rank-step measurement with the stand-in copies excluded)."""
+    from tokenflow_amd.comm import HipComm
+    send = torch.arange(8 * 64, device="cuda", dtype=torch.float32).view(8, 64).bfloat16()
+    for copies in (True, False):
+        comm = HipComm.loopback(3, 8, copies=copies)
+        recv = torch.zeros_like(send)
+        comm.all_to_all_rows(send, recv)
+        bank = torch.zeros(8, 64, device="cuda", dtype=torch.bfloat16)
+        comm.allgather(send[:1], bank)
+        got = [torch.zeros(64, device="cuda", dtype=torch.bfloat16)]
+        comm.sendrecv([send[0]], 4, got, 2)
+        torch.cuda.synchronize()
+        moved = bool(recv.any()) or bool(bank.any()) or bool(got[0].any())
+        assert moved == copies
+        if copies:
+            assert torch.equal(recv, send) and torch.equal(bank, send[:1].expand(8, 64)) and torch.equal(got[0], send[0])
+        comm.close()
+
+
 def _hooks_gpu_worker(rank, world, port, K, inject, native, ret):
     """The drop-in hooks sharded over ranks (register_frame_shard) with the REAL kernels under autocast: each rank's
     block outputs equal the one-process hooks' bit for bit."""

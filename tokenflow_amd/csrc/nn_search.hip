@@ -31,13 +31,13 @@
 
 namespace {
 
-constexpr int TM = 128;  // pivots per tile
-// byte offset of 16-B piece `piece` of row `row` in a [rows][BK] 16-bit tile, BK = 64 or 128 (D chunk).
-// 128-B rows: two rows share a 256-B bank row -> XOR by (row >> 1) & 7; 256-B rows: XOR by row & 15.
+// byte offset of 16-B piece `piece` of row `row` in a [rows][BK] 16-bit tile, BK = 64, 128 or 256 (D chunk).
+// 128-B rows: two rows share a 256-B bank row -> XOR by (row >> 1) & 7; 256-B and 512-B rows: XOR by row & 15
+// (16 consecutive rows reading the same piece fall into 16 different 16-B bank groups).
 template <int BK>
 __device__ __forceinline__ int swz_off(int row, int piece) {
     if constexpr (BK == 64) return row * 128 + ((piece ^ ((row >> 1) & 7)) << 4);
-    return row * 256 + ((piece ^ (row & 15)) << 4);
+    return row * (BK * 2) + ((piece ^ (row & 15)) << 4);
 }
 
 // ---------------------------------------------------------------------------
@@ -56,9 +56,10 @@ __global__ __launch_bounds__(256) void pivot_inv_norm_kernel(const typename T::e
 
 // ---------------------------------------------------------------------------
 // WN = 32-target sub-tiles per wave (1 or 2): workgroup covers TN = 64*WN targets.
-// BK = D chunk per barrier interval: 64, or 128 for small problems (few workgroups, where the per-iteration
+// BK = D chunk per barrier interval: 64, or 128 / 256 for small problems (few workgroups, where the per-iteration
 //      global-load latency is exposed: halving the iteration count halves the run time).
-template <typename T, int WN, int BK>
+// TM = pivots per tile: 128, or 64 with BK = 256 (the LDS holds two (TM + TN) x BK stages).
+template <typename T, int WN, int BK, int TM>
 __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* __restrict__ tgt,
                                                         const typename T::elem* __restrict__ piv,
                                                         const float* __restrict__ inv_norm,
@@ -67,6 +68,8 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
                                                         int D, int kf0, int kf1, int tiles_per_split, NnChunks ch) {
     typedef typename T::vec8 vec8;
     constexpr int TN = 64 * WN;
+    constexpr int NI = TM / 64;              // 32-pivot sub-tiles per wave
+    constexpr int WR = 32 * NI;              // pivot rows per wave half
     constexpr int PPR = BK / 8;              // 16-B pieces per chunk row
     constexpr int A_BYTES = TM * BK * 2;
     constexpr int B_BYTES = TN * BK * 2;
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wr = wave >> 1;  // pivot half  (rows wr*64 .. +63 of the tile)
+    const int wr = wave >> 1;  // pivot half  (rows wr*WR .. +WR-1 of the tile)
     const int wc = wave & 1;   // target half (cols wc*32*WN .. )
     const int hi = lane >> 5;
     const int l31 = lane & 31;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
         if (kc == 0 && tid < TM) sInv[(mt & 1) * TM + tid] = rinv;
     };
 
-    f32x16 acc[2][WN];
+    f32x16 acc[NI][WN];
     float best_v[WN];
     int best_i[WN];
 #pragma unroll
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
         if (it + 2 < total) stage_load(it + 2, CUR);
         if (kc == 0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
 #pragma unroll
@@ -195,15 +198,15 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
         const unsigned char* b = sB(it & 1);
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            vec8 fa[2], fb[WN];
+            vec8 fa[NI], fb[WN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                fa[i] = __builtin_bit_cast(vec8, ld16(a + swz_off<BK>(wr * 64 + i * 32 + l31, ks * 2 + hi)));
+            for (int i = 0; i < NI; ++i)
+                fa[i] = __builtin_bit_cast(vec8, ld16(a + swz_off<BK>(wr * WR + i * 32 + l31, ks * 2 + hi)));
 #pragma unroll
             for (int j = 0; j < WN; ++j)
                 fb[j] = __builtin_bit_cast(vec8, ld16(b + swz_off<BK>((wc * WN + j) * 32 + l31, ks * 2 + hi)));
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j) acc[i][j] = T::mfma32(fa[i], fb[j], acc[i][j]);
         }
@@ -211,10 +214,10 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
             // argmax epilogue: rows visited in ascending order, strict '>' keeps the first maximum
             const float* si = sInv + (mt & 1) * TM;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NI; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int rl = wr * 64 + i * 32 + cd_row(r, hi);
+                    const int rl = wr * WR + i * 32 + cd_row(r, hi);
                     const float w = si[rl];
                     const int gi = (mt0 + mt) * TM + rl;
 #pragma unroll
@@ -404,9 +407,15 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const NnPartial* __res
 }
 
 // Launch plan shared by the launchers and tf_nn_search_workspace_bytes.
+enum NnKernel {
+    NN_RB,      // register-B kernel (D == 320): 128-target panels, 32-pivot tiles
+    NN_WIDE,    // generic kernel, 128-target panels, 64-wide D chunks
+    NN_BK64,    // generic kernel, 64-target panels, 64-wide D chunks
+    NN_BK128,   // few workgroups and a long contraction: 128-wide D chunks
+    NN_DEEP     // fewer still, D >= 1024: 64-pivot tiles and 256-wide D chunks (a quarter of the barrier intervals)
+};
 struct NnPlan {
-    bool rb;        // register-B kernel (D == 320)
-    bool wide;      // generic kernel with 128-target panels
+    int kern;
     int64_t panels;
     int splits, tiles_per_split;
 };
@@ -427,22 +436,41 @@ static int nn_min_wgs(int C) {
 // n_tgt = targets of ONE chunk, C = chunks in the launch (grid.x = C * panels).
 static NnPlan nn_plan(int64_t n_tgt, int S, int D, int P, int C = 1) {
     NnPlan pl;
-    pl.rb = D == 320;
+    auto shape = [&](int tn, int tm) {
+        pl.panels = (n_tgt + tn - 1) / tn;
+        const int n_tiles = (S + tm - 1) / tm;
+        int splits = 1;
+        // a multi-chunk launch keeps >= 128 pivots per split: below that the per-workgroup fixed cost (target
+        // fragments, partial results, their merge) outweighs the finer tail (cfg1 level 0: 41.8 us at 128 pivots /
+        // split, 72 us at 32)
+        const int min_tiles = C > 1 ? (128 + tm - 1) / tm : 1;
+        while (pl.panels * C * P * splits < nn_min_wgs(C) && splits * 2 <= n_tiles && n_tiles / (splits * 2) >= min_tiles)
+            splits *= 2;
+        pl.tiles_per_split = (n_tiles + splits - 1) / splits;
+        pl.splits = (n_tiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
+        return pl.panels * C * P * pl.splits;   // workgroups of the launch
+    };
+    if (D == 320) {
+        pl.kern = NN_RB;
+        shape(128, 32);
+        return pl;
+    }
     // 128-target panels halve the pivot re-reads; they pay as soon as the grid still fills the GPU after
     // splitting the pivot range (measured at cfg2 level 1, 5120 targets x 2 keyframes: 34.6 vs 39.8 us)
-    pl.wide = !pl.rb && ((n_tgt + 127) / 128) * P * C >= 64;
-    const int tn = pl.rb ? 128 : (pl.wide ? 128 : 64);
-    const int tm = pl.rb ? 32 : TM;
-    pl.panels = (n_tgt + tn - 1) / tn;
-    const int n_tiles = (S + tm - 1) / tm;
-    int splits = 1;
-    // a multi-chunk launch keeps >= 128 pivots per split: below that the per-workgroup fixed cost (target fragments,
-    // partial results, their merge) outweighs the finer tail (cfg1 level 0: 41.8 us at 128 pivots / split, 72 us at 32)
-    const int min_tiles = C > 1 ? (128 + tm - 1) / tm : 1;
-    while (pl.panels * C * P * splits < nn_min_wgs(C) && splits * 2 <= n_tiles && n_tiles / (splits * 2) >= min_tiles)
-        splits *= 2;
-    pl.tiles_per_split = (n_tiles + splits - 1) / splits;
-    pl.splits = (n_tiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
+    if (((n_tgt + 127) / 128) * P * C >= 64) {
+        pl.kern = NN_WIDE;
+        shape(128, 128);
+        return pl;
+    }
+    // few workgroups and a long contraction: the loop is a chain of load -> LDS -> barrier -> MFMA steps whose
+    // latency nothing hides -> wider D chunks (fewer steps)
+#ifndef TF_TUNE_NN_NO_DEEP   // A/B switch of tools/build_variants.sh
+    if (D >= 1024 && shape(64, 64) <= 512) {
+        pl.kern = NN_DEEP;
+        return pl;
+    }
+#endif
+    pl.kern = (shape(64, 128) <= 512 && D >= 512) ? NN_BK128 : NN_BK64;
     return pl;
 }
 
@@ -455,15 +483,16 @@ static int finalize(const NnPartial* part, int32_t* idx, int64_t total, int spli
 
 // n_tgt = targets per chunk; C chunks per launch (C = 1, first_single = 0: the plain single-chunk search).
 // Partial results / indices are laid out over all C * n_tgt targets.
-template <typename T, int WN, int BK>
+template <typename T, int WN, int BK, int TM>
 int launch_nn(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, NnPartial* ws, int64_t n_tgt,
               int S, int D, int P, int kf0, int kf1, hipStream_t st, bool fin, int C, int first_single) {
     constexpr int TN = 64 * WN;
-    const size_t lds = 2 * (TM + TN) * BK * 2 + 2 * TM * 4 + 2 * TN * 8;
+    constexpr size_t lds = 2 * (TM + TN) * BK * 2 + 2 * TM * 4 + 2 * TN * 8;
+    static_assert(lds <= 160 * 1024, "LDS");
     const NnPlan pl = nn_plan(n_tgt, S, D, P, C);
     const int splits = pl.splits, tps = pl.tiles_per_split;
     dim3 grid((unsigned)(pl.panels * C), (unsigned)P, (unsigned)splits);
-    auto kern = nn_search_kernel<T, WN, BK>;
+    auto kern = nn_search_kernel<T, WN, BK, TM>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const NnChunks ch{n_tgt, (int)pl.panels, first_single};
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, reinterpret_cast<const typename T::elem*>(tgt),
@@ -492,15 +521,18 @@ int launch_nn_rb(const void* tgt, const void* piv, const float* inv_norm, int32_
 template <typename T>
 int dispatch_nn(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, NnPartial* ws, int64_t n_tgt,
                 int S, int D, int P, int kf0, int kf1, hipStream_t st, bool fin, int C = 1, int first_single = 0) {
-    const NnPlan pl = nn_plan(n_tgt, S, D, P, C);
-    if (pl.rb) return launch_nn_rb<T, 20>(tgt, piv, inv_norm, idx, ws, n_tgt, S, P, kf0, kf1, st, fin, C, first_single);
-    // 128-target panels for all but the small target sets (nn_plan), else 64-target panels
-    if (pl.wide)
-        return launch_nn<T, 2, 64>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin, C, first_single);
-    // few workgroups and a long contraction: latency-bound per iteration -> 128-wide D chunks
-    if (pl.panels * C * P * pl.splits <= 512 && D >= 512)
-        return launch_nn<T, 1, 128>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin, C, first_single);
-    return launch_nn<T, 1, 64>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin, C, first_single);
+    switch (nn_plan(n_tgt, S, D, P, C).kern) {
+        case NN_RB:
+            return launch_nn_rb<T, 20>(tgt, piv, inv_norm, idx, ws, n_tgt, S, P, kf0, kf1, st, fin, C, first_single);
+        case NN_WIDE:
+            return launch_nn<T, 2, 64, 128>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin, C, first_single);
+        case NN_DEEP:
+            return launch_nn<T, 1, 256, 64>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin, C, first_single);
+        case NN_BK128:
+            return launch_nn<T, 1, 128, 128>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin, C, first_single);
+        default:
+            return launch_nn<T, 1, 64, 128>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin, C, first_single);
+    }
 }
 
 }  // namespace

@@ -38,7 +38,7 @@ __all__ = [
     "register_pivotal", "register_batch_idx", "register_time", "load_source_latents_t",
     "register_conv_injection", "register_extended_attention_pnp", "register_extended_attention",
     "make_tokenflow_attention_block", "set_tokenflow", "isinstance_str", "batch_cosine_sim",
-    "register_frame_shard",
+    "register_frame_shard", "join_frame_shard",
 ]
 
 
@@ -96,6 +96,20 @@ def register_frame_shard(diffusion_model, shard):
         module.__dict__["_tf_shard"] = shard
         module.__dict__.pop("_tf_halo", None)
         module.attn1.__dict__["_tf_shard"] = shard
+
+
+def join_frame_shard(diffusion_model):
+    """Order the CURRENT stream behind every neighbour halo of the pivotal pass that is still in flight.  The chunk
+    passes do that themselves, block by block, the first time they read a block's halo slot -- which lets the halos
+    travel under the rest of the pivotal pass; call this at the end of a pivotal pass that is captured into a HIP
+    graph (tokenflow_amd.graphs.GraphCache): a capture must join every stream it forked before it ends, and the chunk
+    passes' graphs then contain no wait on another graph's events."""
+    for module in _tokenflow_blocks(diffusion_model):
+        shard = module.__dict__.get("_tf_shard")
+        halo = module.__dict__.get("_tf_halo")
+        if shard is not None and halo is not None and halo[3]:
+            shard.halo_wait(halo[3])
+            module.__dict__["_tf_halo"] = (halo[0], halo[1], halo[2], [])
 
 
 def _active_shard(module):

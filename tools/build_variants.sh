@@ -5,11 +5,12 @@ set -e
 cd "$(dirname "$0")/../tokenflow_amd/csrc"
 OUT=../../build/variants
 mkdir -p $OUT
-BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form"
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form"
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   /opt/rocm/bin/hipcc $BASE -fno-honor-nans $flags -c ext_attn.hip -o $OUT/ext_attn_$name.o
+  /opt/rocm/bin/hipcc $BASE -fno-honor-nans $flags -c ext_attn_fused.hip -o $OUT/ext_attn_fused_$name.o
   /opt/rocm/bin/hipcc $BASE $flags -c nn_search.hip -o $OUT/nn_search_$name.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC tf_abi.o gather_blend.o layer_norm.o head_exchange.o ddim_step.o comm.o rank_exec.o $OUT/nn_search_$name.o $OUT/ext_attn_$name.o -ldl -o $OUT/lib_$name.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC tf_abi.o gather_blend.o layer_norm.o head_exchange.o ddim_step.o comm.o rank_exec.o $OUT/nn_search_$name.o $OUT/ext_attn_fused_$name.o $OUT/ext_attn_$name.o -ldl -o $OUT/lib_$name.so
   echo built $OUT/lib_$name.so
 done

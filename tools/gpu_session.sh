@@ -14,6 +14,11 @@ for stage in "$@"; do
     kerneltests) timeout 1500 python -m pytest tests/test_kernels_gpu.py -q --tb=line -p no:cacheprovider -k "attn" 2>&1 | tail -30 > $O/kernel_attn_tests.txt; tail -15 $O/kernel_attn_tests.txt ;;
     shardtests) timeout 1500 python -m pytest tests/test_sharded_gpu.py -q --tb=short -p no:cacheprovider -x 2>&1 | tail -40 > $O/sharded_tests.txt; tail -15 $O/sharded_tests.txt ;;
     alltests)   timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x 2>&1 | tail -40 > $O/all_gpu_tests.txt; tail -15 $O/all_gpu_tests.txt ;;
+    nntests)    timeout 900 python -m pytest tests/test_kernels_gpu.py -q --tb=line -p no:cacheprovider -k "nn_search or propagat" 2>&1 | tail -15 ;;
+    abprev)     # A/B against build/variants/lib_prev.so (tools/build_variants.sh prev "<flags>")
+                for lib in "" build/variants/lib_prev.so; do echo "--- lib: ${lib:-current}" | tee -a $O/ab_prev.txt
+                  TOKENFLOW_HIP_LIB=$lib timeout 300 python tools/nn_microbench.py 8,5,256,1280 8,5,64,1280 4,4,64,1280 4,4,16,1280 2>/dev/null | tee -a $O/ab_prev.txt
+                  TOKENFLOW_HIP_LIB=$lib timeout 300 python tools/fused_microbench.py --only "L1" --reps 10 2>/dev/null | cut -c1-330 | tee -a $O/ab_prev.txt; done ;;
     fusedbench) timeout 600 python tools/fused_microbench.py > $O/fused_microbench.txt 2>&1; tail -40 $O/fused_microbench.txt ;;
     rankstep)   timeout 600 python tools/rank_step_microbench.py --native --only split,auto > $O/rank_step_native.txt 2>&1; tail -14 $O/rank_step_native.txt
                 timeout 300 python tools/rank_step_microbench.py --native --only split,auto --no-copies --no-levels > $O/rank_step_native_nocopies.txt 2>&1; tail -3 $O/rank_step_native_nocopies.txt
@@ -37,7 +42,9 @@ for stage in "$@"; do
                 python tools/rocpd_stats.py $(find /tmp/kt1 -name "*_results.db" | head -1) > $O/cfg1_kernel_stats.csv; head -30 $O/cfg1_kernel_stats.csv | cut -c1-190 ;;
     othercfgs)  for cfg in cfg4 cfg5; do timeout 600 python bench.py --config $cfg --no-cpu-baseline --no-yardstick --steps 3 --warmup 1 > $O/bench_$cfg.json 2>$O/bench_$cfg.err; python -c "import json;d=json.load(open('$O/bench_$cfg.json'));print('$cfg',d['ms_per_step'],d['parity']['attn_linf'],d['parity']['attn_linf_fp32_out'],d['parity']['nn_mismatch_rate'])"; done ;;
     hooks)      for a in "" "--graph" "--graph --all-chunks"; do timeout 600 python tools/hooks_bench.py cfg2 6 $a >> $O/hooks_bench.txt 2>/dev/null; done
-                for a in "--ranks 8" "--ranks 8 --wire-less"; do timeout 600 python tools/hooks_bench.py cfg2 10 $a >> $O/hooks_bench.txt 2>>$O/hooks_bench.err; done; cat $O/hooks_bench.txt ;;
+                for a in "--ranks 8" "--ranks 8 --wire-less" "--ranks 8 --graph" "--ranks 8 --wire-less --graph"; do timeout 600 python tools/hooks_bench.py cfg2 10 $a >> $O/hooks_bench.txt 2>>$O/hooks_bench.err; done; cat $O/hooks_bench.txt ;;
+    hookranks)  for a in "--ranks 8" "--ranks 8 --wire-less" "--ranks 8 --graph" "--ranks 8 --wire-less --graph"; do timeout 600 python tools/hooks_bench.py cfg2 10 $a >> $O/hooks_ranks.txt 2>>$O/hooks_ranks.err; done; cat $O/hooks_ranks.txt; grep -v amdgpu.ids $O/hooks_ranks.err | tail -20 ;;
+    newtests)   timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "sharded_rank or loopback_transport or into_caller or nn_search_shapes" 2>&1 | tail -30 ;;
     hooktests)  timeout 1500 python -m pytest tests/test_baseline_configs_gpu.py tests/test_sharded_gpu.py -q --tb=short -p no:cacheprovider -x -k "hooks or hipgraph or cfg1" 2>&1 | tail -15 ;;
     gloo8)      timeout 900 python bench.py --gpus 8 --backend gloo --steps 2 --warmup 1 > $O/bench_gloo8.txt 2>&1; tail -c 1500 $O/bench_gloo8.txt ;;
     *) echo "unknown stage $stage" ;;

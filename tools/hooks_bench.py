@@ -13,7 +13,9 @@ calls the ops directly on pre-made tensors.
                     ONE rank of a W-GPU frame-sharded run through the hook API (register_frame_shard with a NativeShard on
                     the library's loopback transport: every exchange a same-size local copy; --wire-less: no copies at
                     all): the rank's Kl keyframes in the pivotal pass, its own chunks in the chunk passes.  Compare with
-                    tools/rank_step_microbench.py --native (the same rank through bench.py's direct op calls).
+                    tools/rank_step_microbench.py --native (the same rank through bench.py's direct op calls).  With
+                    --graph the rank's passes replay from HIP graphs (loopback exchanges are stream-ordered copies; the
+                    pivotal pass ends with hooks.join_frame_shard): the hook-level rank step without Python issue time.
 """
 import os
 import sys
@@ -104,7 +106,10 @@ def main():
 
     def pivotal_pass(*xs):
         tfu.register_pivotal(holder, True)
-        return [blk(x) for (blk, _, _), x in zip(blocks, xs)]
+        out = [blk(x) for (blk, _, _), x in zip(blocks, xs)]
+        if shard is not None and cache is not None:
+            hooks.join_frame_shard(holder)      # a captured pass joins the halo stream before it ends
+        return out
 
     def chunk_pass(c, *xs):
         tfu.register_pivotal(holder, False)
