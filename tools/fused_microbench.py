@@ -50,6 +50,7 @@ SHAPES = [
     ("cfg2 L2  1 GPU", 8, 256, 8, 160, "all"), ("cfg2 L3  1 GPU", 8, 64, 8, 160, "all"),
     ("cfg1 L0  1 GPU", 4, 1024, 8, 40, "all"), ("cfg1 L1  1 GPU", 4, 256, 8, 80, "all"),
     ("cfg1 L2  1 GPU", 4, 64, 8, 160, "all"), ("cfg1 L3  1 GPU", 4, 16, 8, 160, "all"),
+    ("rank/8 L0 source", 1, 4096, 8, 40, "source"),
     ("rank/8 L1 bank", 8, 1024, 1, 80, "bank"), ("rank/8 L1 source", 1, 1024, 8, 80, "source"),
     ("rank/8 L2 bank", 8, 256, 1, 160, "bank"), ("rank/8 L2 source", 1, 256, 8, 160, "source"),
     ("rank/8 L3 bank", 8, 64, 1, 160, "bank"), ("rank/8 L3 source", 1, 64, 8, 160, "source"),
