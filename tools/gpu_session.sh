@@ -44,6 +44,8 @@ for stage in "$@"; do
     hooks)      for a in "" "--graph" "--graph --all-chunks"; do timeout 600 python tools/hooks_bench.py cfg2 6 $a >> $O/hooks_bench.txt 2>/dev/null; done
                 for a in "--ranks 8" "--ranks 8 --wire-less" "--ranks 8 --graph" "--ranks 8 --wire-less --graph"; do timeout 600 python tools/hooks_bench.py cfg2 10 $a >> $O/hooks_bench.txt 2>>$O/hooks_bench.err; done; cat $O/hooks_bench.txt ;;
     hookranks)  for a in "--ranks 8" "--ranks 8 --wire-less" "--ranks 8 --graph" "--ranks 8 --wire-less --graph"; do timeout 600 python tools/hooks_bench.py cfg2 10 $a >> $O/hooks_ranks.txt 2>>$O/hooks_ranks.err; done; cat $O/hooks_ranks.txt; grep -v amdgpu.ids $O/hooks_ranks.err | tail -20 ;;
+    hookrankstrace) rm -rf /tmp/hrt; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/hrt -- python $GRAFT_REPO_ROOT/tools/hooks_bench.py cfg2 10 --ranks 8 --wire-less --graph > /dev/null 2>&1 )
+                python tools/rocpd_stats.py $(find /tmp/hrt -name "*_results.db" | head -1) > $O/hooks_rank_kernel_stats.csv; head -40 $O/hooks_rank_kernel_stats.csv | cut -c1-170 ;;
     newtests)   timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "sharded_rank or loopback_transport or into_caller or nn_search_shapes" 2>&1 | tail -30 ;;
     hooktests)  timeout 1500 python -m pytest tests/test_baseline_configs_gpu.py tests/test_sharded_gpu.py -q --tb=short -p no:cacheprovider -x -k "hooks or hipgraph or cfg1" 2>&1 | tail -15 ;;
     gloo8)      timeout 900 python bench.py --gpus 8 --backend gloo --steps 2 --warmup 1 > $O/bench_gloo8.txt 2>&1; tail -c 1500 $O/bench_gloo8.txt ;;
