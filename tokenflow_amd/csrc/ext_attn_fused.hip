@@ -484,22 +484,29 @@ __global__ __launch_bounds__(64 * KW, 1) void ext_attn_fused_wp_kernel(FusedPara
     }
     const E* qfrag = sQ + l31 * C::KROW + 8 * hi;
 
-    // ---- loads of one sub-tile, one ahead of its use; branch-free (clamped rows / cursor), see the shared-tile form
+    // ---- loads of a sub-tile's K and V, each with its own cursor; branch-free (clamped rows / cursor), see the
+    //      shared-tile form.  K runs TWO sub-tiles ahead of the softmax (its S^T = K Q^T is issued one sub-tile early,
+    //      below), V one.
     u32x4 rk[C::KS], rv[NPH];
     const int v_row = lane >> 1, v_pc0 = (lane & 1) * NPH;
-    Cursor ldc;
-    ldc.init(kw, tpf, nst);
-    int key0_next = 0;
-    auto load_tile = [&]() {
-        const int nvalid = min(32, S - ldc.tt * 32);
-        key0_next = ldc.tt * 32;
-        const E* kb = kg + ldc.fr * k_fs + (int64_t)(ldc.tt * 32) * ld + min(l31, nvalid - 1) * ld + 8 * hi;
-        const E* vb = vg + ldc.fr * v_fs + (int64_t)(ldc.tt * 32) * ld + min(v_row, nvalid - 1) * ld;
+    Cursor ldk, ldv;
+    ldk.init(kw, tpf, nst);
+    ldv.init(kw, tpf, nst);
+    int key0_k = 0;   // first key (inside its frame) of the sub-tile whose K fragments sit in rk
+    auto load_k = [&]() {
+        const int nvalid = min(32, S - ldk.tt * 32);
+        key0_k = ldk.tt * 32;
+        const E* kb = kg + ldk.fr * k_fs + (int64_t)(ldk.tt * 32) * ld + min(l31, nvalid - 1) * ld + 8 * hi;
 #pragma unroll
         for (int t = 0; t < C::KS; ++t) rk[t] = (16 * t + 8 * hi < DH) ? ld16(kb + 16 * t) : u32x4{0, 0, 0, 0};
+        ldk.advance(KW, tpf, nst);
+    };
+    auto load_v = [&]() {
+        const int nvalid = min(32, S - ldv.tt * 32);
+        const E* vb = vg + ldv.fr * v_fs + (int64_t)(ldv.tt * 32) * ld + min(v_row, nvalid - 1) * ld;
 #pragma unroll
         for (int i = 0; i < NPH; ++i) rv[i] = ld16(vb + min(v_pc0 + i, C::PPR - 1) * 8);
-        ldc.advance(KW, tpf, nst);
+        ldv.advance(KW, tpf, nst);
     };
 
     f32x16 o[QB][C::MT];
@@ -517,27 +524,46 @@ __global__ __launch_bounds__(64 * KW, 1) void ext_attn_fused_wp_kernel(FusedPara
     const int li = lane & 15, lg = lane >> 4;
     const E* vtr = sV + (4 * hi + (li >> 2)) * C::VS + 16 * (lg & 1) + 4 * (li & 3);
 
-    load_tile();
+    // S^T = K Q^T of the sub-tile in rk (k-step outermost: consecutive MFMAs hit different accumulators)
+    f32x16 s_next[QB];
+    int key0_next = 0;
+    auto qk = [&]() {
+        key0_next = key0_k;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) s_next[qb] = zero;
+#pragma unroll
+        for (int t = 0; t < C::KS; ++t)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const vec8 qv = LQ ? __builtin_bit_cast(vec8, ld16(qfrag + 16 * t)) : qf[qb][LQ ? 0 : t];
+                s_next[qb] = T::mfma32(__builtin_bit_cast(vec8, rk[t]), qv, s_next[qb]);
+            }
+    };
+
+    // Software pipeline over this wave's sub-tiles: the QK^T MFMAs of sub-tile i+1 are issued BEFORE the softmax of
+    // sub-tile i, so the matrix pipe works through them while the wave's VALU does the exponentials -- without it a
+    // barrier-free wave runs its MFMAs and its softmax strictly one after the other (352 + 230 clk per sub-tile at
+    // Dh = 80).  Same arithmetic, same order per (query, key): bit-identical results.
+    load_k();
+    load_v();
+    qk();        // sub-tile 0
+    load_k();    // sub-tile 1 (past the end: a harmless re-load)
     for (int i = 0; i < nmine; ++i) {
-        const int key0 = key0_next;
         // V(i) -> this wave's LDS region (the transpose reads of sub-tile i-1 precede these writes in the wave's
         // in-order LDS stream)
 #pragma unroll
         for (int j2 = 0; j2 < NPH; ++j2)
             if (v_pc0 + j2 < C::PPR) st16(sV + v_row * C::VS + (v_pc0 + j2) * 8, rv[j2]);
         __builtin_amdgcn_wave_barrier();
-        // S^T = K Q^T from the register-resident K fragments (k-step outermost: consecutive MFMAs hit different accumulators)
+        load_v();    // V(i+1) flies under everything below
         f32x16 s[QB];
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) s[qb] = zero;
-#pragma unroll
-        for (int t = 0; t < C::KS; ++t)
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                const vec8 qv = LQ ? __builtin_bit_cast(vec8, ld16(qfrag + 16 * t)) : qf[qb][LQ ? 0 : t];
-                s[qb] = T::mfma32(__builtin_bit_cast(vec8, rk[t]), qv, s[qb]);
-            }
-        load_tile();   // K(i+1), V(i+1) fly under the softmax and the P.V MFMAs (past the end: a harmless re-load)
+        for (int qb = 0; qb < QB; ++qb) s[qb] = s_next[qb];
+        const int key0 = key0_next;
+        if (i + 1 < nmine) {
+            qk();        // sub-tile i+1: executes under the softmax of sub-tile i
+            load_k();    // sub-tile i+2
+        }
         vec8 ph[QB][2], pl[QB][2];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
