@@ -46,6 +46,11 @@ for stage in "$@"; do
     hookranks)  for a in "--ranks 8" "--ranks 8 --wire-less" "--ranks 8 --graph" "--ranks 8 --wire-less --graph"; do timeout 600 python tools/hooks_bench.py cfg2 10 $a >> $O/hooks_ranks.txt 2>>$O/hooks_ranks.err; done; cat $O/hooks_ranks.txt; grep -v amdgpu.ids $O/hooks_ranks.err | tail -20 ;;
     hookrankstrace) rm -rf /tmp/hrt; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/hrt -- python $GRAFT_REPO_ROOT/tools/hooks_bench.py cfg2 10 --ranks 8 --wire-less --graph > /dev/null 2>&1 )
                 python tools/rocpd_stats.py $(find /tmp/hrt -name "*_results.db" | head -1) > $O/hooks_rank_kernel_stats.csv; head -40 $O/hooks_rank_kernel_stats.csv | cut -c1-170 ;;
+    fusedpmc)   ( cd /tmp && rocprofv3 -L 2>/dev/null | grep -o "\(TCP\|TCC\|TA\|TD\|SQ\)_[A-Z0-9_a-z]*" | sort -u | tr "\n" " " | cut -c1-6000 ) > $O/pmc_counters_avail.txt
+                for grp in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TA_BUSY_avr TCC_REQ_sum"; do
+                  rm -rf /tmp/fp; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/fp -- python $GRAFT_REPO_ROOT/tools/fused_pmc_target.py > /dev/null 2>>$GRAFT_REPO_ROOT/$O/fusedpmc.err )
+                  DB=$(find /tmp/fp -name "*_results.db" | head -1); [ -n "$DB" ] && python tools/rocpd_pmc.py $DB | grep -v "at::native" >> $O/pmc_fused.csv; done
+                cat $O/pmc_fused.csv | cut -c1-200; tail -3 $O/fusedpmc.err ;;
     newtests)   timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "sharded_rank or loopback_transport or into_caller or nn_search_shapes" 2>&1 | tail -30 ;;
     hooktests)  timeout 1500 python -m pytest tests/test_baseline_configs_gpu.py tests/test_sharded_gpu.py -q --tb=short -p no:cacheprovider -x -k "hooks or hipgraph or cfg1" 2>&1 | tail -15 ;;
     gloo8)      timeout 900 python bench.py --gpus 8 --backend gloo --steps 2 --warmup 1 > $O/bench_gloo8.txt 2>&1; tail -c 1500 $O/bench_gloo8.txt ;;
