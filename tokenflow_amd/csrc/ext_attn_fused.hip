@@ -17,8 +17,8 @@
 //     P -- the dominant error term where few keys are averaged (the reference rounds P to fp16, 2^-11, at the same
 //     point: tokenflow_utils.py:177-179 under run_tokenflow_pnp.py:220).  f16 inputs carry P as f16 (11 bits).
 // MFMA mapping as in ext_attn.hip: S^T = K Q^T (a lane owns one query and 16 of the sub-tile's 32 keys), O^T = V^T P.
-// Online softmax per 32-key sub-tile with the true running maximum (no deferred shift: P <= 1, which keeps the f16
-// form exact in range); the rescale is skipped (wave-uniform) when no query of the wave saw a new maximum.
+// Online softmax per 32-key sub-tile against a per-query reference point that follows the running maximum with a lag
+// of TF_FUSED_LAG binades (P <= 2^8: in range for f16 as well); O is rescaled only when a reference moves (softmax_p).
 // Arithmetic of a (query, head) depends on KW and PREC only -- never on QW or on the grid -- so a rank reproduces the
 // single-GPU result bit for bit whenever both take this kernel with the same KW (tf_attn_fused_plan: shape-only rules
 // in TF_ATTN_NO_SPLIT mode).
@@ -79,6 +79,7 @@ struct FusedParams {
     unsigned tpf_magic;        // j / tpf = umulhi(j, tpf_magic) for tpf > 1
     int inject, out_f32;
     float c;                   // scale * log2(e)
+    float lag;                 // TF_FUSED_LAG / c: raw score units the sub-tile maximum may exceed a query's reference by
 };
 
 __device__ __forceinline__ float max_xor32(float x) {
@@ -144,21 +145,32 @@ struct Cursor {
     }
 };
 
-// online softmax of one 32-key sub-tile (lane-local; the two lanes of a query share the maximum): rescales O when the
-// running maximum of some query of the wave moved, leaves P of the two 16-key k-steps (registers 0-7 / 8-15 of the
-// accumulator) in ph (and the rounding remainders in pl with PREC)
+// online softmax of one 32-key sub-tile (lane-local; the two lanes of a query share the maximum): moves the query's
+// reference point m_run -- and rescales O -- only when the sub-tile's maximum exceeds it by more than `lag` raw score units
+// (= TF_FUSED_LAG binades of P), leaves P of the two 16-key k-steps (registers 0-7 / 8-15 of the accumulator) in ph (and
+// the rounding remainders in pl with PREC).
+// The reference point need not be the running maximum: any m gives the same softmax as long as numerator and denominator
+// use it, and P <= 2^TF_FUSED_LAG is harmless in bf16 / f16 / fp32 (P keeps its relative precision).  With the exact
+// running maximum a wave of 32 queries rescaled on 54 of its 64 sub-tiles (some query almost always sees a new maximum:
+// expected count 32 + 32 ln 2) -- 24 packed multiplies, an exponential and a dependent chain each time; with the lag the
+// reference moves once or twice per query.  The decision is PER QUERY (a query whose maximum did not pass its own
+// reference keeps alpha = 1 exactly), so the arithmetic of a query never depends on its neighbours in the wave.
+#ifndef TF_FUSED_LAG
+#define TF_FUSED_LAG 8
+#endif
 template <typename T, int DH, bool PREC>
 __device__ __forceinline__ void softmax_p(f32x16& s, f32x16 (&o)[FusedCfg<DH>::MT], float& m_run, float& l_run, float c,
-                                          typename T::vec8 (&ph)[2], typename T::vec8 (&pl)[2]) {
+                                          float lag, typename T::vec8 (&ph)[2], typename T::vec8 (&pl)[2]) {
     typedef FusedCfg<DH> C;
     typedef typename T::elem E;
     float mx = s[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
     mx = max_xor32(mx);
-    if (__any(mx > m_run)) {   // wave-uniform: alpha == 1 exactly for every query otherwise
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);   // exp2(-inf) = 0 on the first sub-tile
+    const bool move = mx > m_run + lag;   // -inf + lag = -inf: the first sub-tile always sets the reference
+    if (__any(move)) {
+        const float m_new = move ? mx : m_run;
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);   // exp2(-inf) = 0 on the first sub-tile; 1 if !move
         m_run = m_new;
         l_run *= alpha;
 #pragma unroll
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(64 * QW * KW, 1) void ext_attn_fused_kernel(FusedPa
     for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[0][mt][r] = 0.f;
-    const float c = p.c;
+    const float c = p.c, lag = p.lag;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // fragment addresses inside this wave's slot
@@ -397,7 +409,7 @@ __global__ __launch_bounds__(64 * QW * KW, 1) void ext_attn_fused_kernel(FusedPa
                     if (key0 + cd_row(r, hi) >= S) s[r] = -INFINITY;
             }
             vec8 ph[1][2], pl[1][2];
-            softmax_p<T, DH, PREC>(s, o[0], m_run, l_run, c, ph[0], pl[0]);
+            softmax_p<T, DH, PREC>(s, o[0], m_run, l_run, c, lag, ph[0], pl[0]);
             pv_acc<T, DH, 1, PREC>(o, ph, pl, vtr);
             cc.advance(KW, tpf, nst);
         }
@@ -519,7 +531,7 @@ __global__ __launch_bounds__(64 * KW, 1) void ext_attn_fused_wp_kernel(FusedPara
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[qb][mt][r] = 0.f;
     }
-    const float c = p.c;
+    const float c = p.c, lag = p.lag;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int li = lane & 15, lg = lane >> 4;
     const E* vtr = sV + (4 * hi + (li >> 2)) * C::VS + 16 * (lg & 1) + 4 * (li & 3);
@@ -572,7 +584,7 @@ __global__ __launch_bounds__(64 * KW, 1) void ext_attn_fused_wp_kernel(FusedPara
                 for (int r = 0; r < 16; ++r)
                     if (key0 + cd_row(r, hi) >= S) s[qb][r] = -INFINITY;
             }
-            softmax_p<T, DH, PREC>(s[qb], o[qb], m_run[qb], l_run[qb], c, ph[qb], pl[qb]);
+            softmax_p<T, DH, PREC>(s[qb], o[qb], m_run[qb], l_run[qb], c, lag, ph[qb], pl[qb]);
         }
         pv_acc<T, DH, QB, PREC>(o, ph, pl, vtr);
         __builtin_amdgcn_wave_barrier();
@@ -720,6 +732,7 @@ int tf_attn_fused_launch(const TfAttnSet* sets, int n_sets, int S, int Dh, float
     p.inject = (flags & TF_ATTN_INJECT) ? 1 : 0;
     p.out_f32 = (flags & TF_ATTN_OUT_F32) ? 1 : 0;
     p.c = (float)((double)scale * 1.4426950408889634);
+    p.lag = (float)TF_FUSED_LAG / p.c;
     int64_t grid = 0;
     for (int i = 0; i < n_sets; ++i) {
         const TfAttnSet& a = sets[i];
