@@ -38,6 +38,11 @@
 #include "attn_fused.h"
 #include "tf_common.h"
 
+// Binades by which a query's softmax reference point may trail its running maximum (kernels without the score bound)
+#ifndef TF_ATTN_LAG
+#define TF_ATTN_LAG 8.0f
+#endif
+
 namespace {
 
 template <int DH, int KT>   // KT = keys per staged tile (one barrier interval): 64 or 128
@@ -540,10 +545,12 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
                             if (over) m_new = mx;
                         }
                     } else {
+                        // reference point = running maximum with a lag of 8 binades (see ext_attn_il_kernel): per-query
+                        // decision, alpha == 1 exactly for a query whose reference stays
                         const float mx = tile_max();
-                        // rescale only when some query of this wave saw a new maximum: alpha == 1 exactly otherwise
-                        move = __any(mx > m_run[qi]);
-                        m_new = fmaxf(m_run[qi], mx);
+                        const bool over = mx > m_run[qi] + TF_ATTN_LAG / c;
+                        move = __any(over);
+                        m_new = over ? mx : m_run[qi];
                     }
                     if (move) {
                         const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);  // exp2(-inf) = 0 on tile 0
@@ -1025,8 +1032,9 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
             }
             return 0.f;
         }
-        if (__any(mx > m_run[qi])) {
-            const float m_new = fmaxf(m_run[qi], mx);
+        const bool over = mx > m_run[qi] + TF_ATTN_LAG / c;   // lagged reference point (see ext_attn_il_kernel), per query
+        if (__any(over)) {
+            const float m_new = over ? mx : m_run[qi];
             const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);
             m_run[qi] = m_new;
             if constexpr (!ONES) l_run[qi] *= alpha;
@@ -1344,7 +1352,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
 
     f32x16 o[MT], s[2];
     vec8 pf[2][2];      // P of the two 32-key halves, two 16-key k-steps each
-    float m_run = -INFINITY;   // BOUND: deferred shift; else the running maximum (raw-score units)
+    float m_run = -INFINITY;   // BOUND: deferred shift; else the lagged running maximum (raw-score units)
+    const float lag = TF_ATTN_LAG / c;   // raw-score units
     float l_run = 0.f;         // !ONES: this lane's share of the denominator
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -1381,10 +1390,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
                 }
             }
         } else {
+            // m_run = the query's reference point: it follows the running maximum with a lag of TF_ATTN_LAG binades (P <= 2^8,
+            // in range for f16 too).  With the exact maximum a wave of 32 queries rescaled O on ~40 % of its half tiles
+            // (some query almost always sees a new maximum); per-query decision: alpha = 1 exactly where it did not move.
             const float mx = half_max();
-            if (__any(mx > m_run)) {   // rescale only when some query of this wave saw a new maximum
+            const bool over = mx > m_run + lag;   // -inf + lag = -inf: the first half tile always sets the reference
+            if (__any(over)) {
                 move = true;
-                const float m_new = fmaxf(m_run, mx);
+                const float m_new = over ? mx : m_run;
                 alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
                 m_run = m_new;
             }
