@@ -74,9 +74,10 @@ def test_ext_attn_injection_equals_aliased_inputs(S):
     """inject=True against running without injection on tensors whose uncond/cond q and k were overwritten by the
     source branch's (what the reference does in place, 124-130).  S = 1000: both calls run the same kernel family
     (shared-softmax dual form / plain form: same tile order, same running maximum) and must agree bit for bit.
-    S = 1024: the call without injection takes the half-tile interleaved kernel, whose running maximum moves per 32
-    keys instead of 64 -- P is then rounded against a different shift, so the two agree within the attention bound
-    (2^-8 relative on the output, tests/test_kernels_gpu.py), not bitwise."""
+    S = 1024: the call without injection takes the half-tile interleaved kernel, whose softmax reference point moves
+    per 32 keys instead of 64 -- P is then rounded against a different shift, so the two are independent roundings of
+    the same result: EACH is within 2e-4 + 2^-8 |ref| of it (the attention bound of tests/test_kernels_gpu.py; its
+    P-rounding term averages out over 8192 keys), hence they differ by at most twice that."""
     ops = _ops()
     K, h, d = 8, 8, 80
     g = torch.Generator(device="cuda").manual_seed(7)
@@ -89,7 +90,7 @@ def test_ext_attn_injection_equals_aliased_inputs(S):
         assert torch.equal(a, b)
     else:
         af, bf = a.float(), b.float()
-        assert bool(((af - bf).abs() <= 2.0 ** -7 * bf.abs() + 2e-4).all())
+        assert bool(((af - bf).abs() <= 2.0 ** -7 * bf.abs() + 4e-4).all())
         assert float((af - bf).abs().max()) < 1e-3
 
 
