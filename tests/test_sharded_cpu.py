@@ -317,6 +317,10 @@ def _hooks_worker(rank, world, port, K, inject_t, mode, one_pass_chunks, ret):
                 got_p = blk(x_piv[:, lo:hi].reshape(3 * sh.Kl, S, D),
                             encoder_hidden_states=enc[:, lo:hi].reshape(3 * sh.Kl, 7, -1)).view(3, sh.Kl, S, D)
                 ok = ok and torch.equal(got_p, piv_out[:, lo:hi])
+                if rank % 2 == 1:      # what a captured pivotal pass ends with: the halos waited for here, not in the
+                    from tokenflow_amd import hooks as _hooks       # first chunk pass -- same results either way
+                    _hooks.join_frame_shard(my_p)
+                    ok = ok and blk.__dict__["_tf_halo"][3] == []
                 tfu.register_pivotal(my_p, False)
                 if one_pass_chunks and sh.Kl > 1:      # the rank's chunks in ONE pass (batch_idx = a run)
                     tfu.register_batch_idx(my_p, range(lo, hi))
