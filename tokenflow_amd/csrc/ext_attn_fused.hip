@@ -430,8 +430,9 @@ __global__ __launch_bounds__(64 * QW * KW, 1) void ext_attn_fused_kernel(FusedPa
 //     need no barrier;
 //   * Q: registers; at Dh = 160 (where the accumulators alone are 80 registers) in LDS, shared by the KW waves;
 //   * QB = 2 (head dims <= 80, longer key sequences): a wave owns two 32-query blocks -- every K and V^T fragment it
-//     fetches feeds two MFMAs, which halves the K / V re-reads per query (a wave-private problem is bound by the L1's
-//     64 B/clk once thousands of keys stream through every 32-query tile).
+//     fetches feeds two MFMAs, which halves the K / V re-reads per query.  Opt-in (TF_ATTN_HINT_QB2): on a rank's
+//     level 1 it measured 70-72 against 72-75 us -- the launch is bound by its instruction mix, not by the re-reads
+//     (profiles/r04_pmc_fused.csv) -- at 250+ registers (one wave per SIMD at Dh = 80).
 // Same arithmetic per (query, head) as the shared-tile form with the same KW: bit-identical results.
 template <typename T, int DH, int KW, int QB, bool PREC>
 __global__ __launch_bounds__(64 * KW, 1) void ext_attn_fused_wp_kernel(FusedParams p) {
