@@ -51,6 +51,13 @@ for stage in "$@"; do
                   rm -rf /tmp/fp; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/fp -- python $GRAFT_REPO_ROOT/tools/fused_pmc_target.py > /dev/null 2>>$GRAFT_REPO_ROOT/$O/fusedpmc.err )
                   DB=$(find /tmp/fp -name "*_results.db" | head -1); [ -n "$DB" ] && python tools/rocpd_pmc.py $DB | grep -v "at::native" >> $O/pmc_fused.csv; done
                 cat $O/pmc_fused.csv | cut -c1-200; tail -3 $O/fusedpmc.err ;;
+    pmcl1)      # level-1 kernels: the d = 80 attention and the D = 640 8-chunk search
+                for grp in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"; do
+                  rm -rf /tmp/p1; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/p1 -- python $GRAFT_REPO_ROOT/tools/attn_microbench.py 8,1024,8,80 > /dev/null 2>&1 )
+                  python tools/rocpd_pmc.py $(find /tmp/p1 -name "*_results.db" | head -1) | grep "ext_attn_il_kernel\|^kernel" >> $O/pmc_l1.csv
+                  rm -rf /tmp/p2; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/p2 -- python $GRAFT_REPO_ROOT/tools/prop_microbench.py 8,5,1024,640 > /dev/null 2>&1 )
+                  python tools/rocpd_pmc.py $(find /tmp/p2 -name "*_results.db" | head -1) | grep "nn_search_kernel" | grep "x2x8" >> $O/pmc_l1.csv; done
+                cut -c1-60,100-220 $O/pmc_l1.csv ;;
     newtests)   timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "sharded_rank or loopback_transport or into_caller or nn_search_shapes" 2>&1 | tail -30 ;;
     hooktests)  timeout 1500 python -m pytest tests/test_baseline_configs_gpu.py tests/test_sharded_gpu.py -q --tb=short -p no:cacheprovider -x -k "hooks or hipgraph or cfg1" 2>&1 | tail -15 ;;
     gloo8)      timeout 900 python bench.py --gpus 8 --backend gloo --steps 2 --warmup 1 > $O/bench_gloo8.txt 2>&1; tail -c 1500 $O/bench_gloo8.txt ;;
