@@ -27,6 +27,12 @@ Fixtures
                  syntax tree and executed unchanged on a stand-in model: the latents files written
                  (names + contents), the inverted and the reconstructed latents.  fp32, and float16 as the
                  reference runs them (preprocess.py:195).
+  driver.pt      the hook-facing methods of the reference DRIVERS -- TokenFlow.init_method / denoise_step /
+                 batched_denoise_step, run_tokenflow_pnp.py:195-239 and run_tokenflow_sdedit.py:154-193, cut out of
+                 the syntax tree and executed unchanged (oracle/driver_cut.py) -- over the verbatim hooks on the
+                 runnable stand-in UNet (tests/driver_seam.py), 3 timesteps (q/k + feature injection, feature
+                 injection only, none): the hook-call trace, the `pivotal_idx` draws, the UNet's noise prediction
+                 and every transformer block's output of every UNet call, the latents after each step.
   adazero.pt     TokenFlowBlock.forward on an AdaLayerNormZero block (use_ada_layer_norm_zero:
                  gate_msa on the cached / selected attention outputs, 362-366; scale/shift/gate
                  on the feed-forward, 417-424): pivotal pass and chunks 0..K-1.
@@ -246,6 +252,25 @@ def gen_inversion():
     return out
 
 
+def gen_driver(tfu):
+    """The verbatim driver methods over the verbatim hooks, CPU fp32 (the decorator's CUDA autocast is inert on
+    the CPU).  One record per driver kind."""
+    import tempfile
+    import warnings
+    from oracle import driver_cut
+    from tests import driver_seam as ds
+    out = {}
+    for kind in ("pnp", "sdedit"):
+        log = []
+        methods = driver_cut.load_reference_driver(kind, ds.traced(tfu, log))
+        with tempfile.TemporaryDirectory() as d, warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rec = ds.run_driver(kind, methods, d)
+        rec["trace"] = log
+        out[kind] = rec
+    return out
+
+
 def main():
     tfu, util = ref_loader.load()
     os.makedirs(GOLDEN, exist_ok=True)
@@ -254,6 +279,7 @@ def main():
     torch.save(gen_blocks(tfu), os.path.join(GOLDEN, "blocks.pt"))
     torch.save(gen_adazero(tfu), os.path.join(GOLDEN, "adazero.pt"))
     torch.save(gen_inversion(), os.path.join(GOLDEN, "inversion.pt"))
+    torch.save(gen_driver(tfu), os.path.join(GOLDEN, "driver.pt"))
     for f in sorted(os.listdir(GOLDEN)):
         print(f, os.path.getsize(os.path.join(GOLDEN, f)) // 1024, "KiB")
 

@@ -184,3 +184,69 @@ class FakePipeline(nn.Module):
         super().__init__()
         self.unet = FakeUNet(**kw)
         self.text_encoder = nn.Linear(4, 4)
+
+
+# ----------------------------------------------------------------------------------- a UNet the DRIVER can call
+class RunnableUNet(FakeUNet):
+    """`FakeUNet` with a forward pass, so that the reference's driver methods (`denoise_step`,
+    /root/reference/run_tokenflow_pnp.py:195-217) can call `self.unet(latents, t, encoder_hidden_states=...)['sample']`.
+    Same module tree as the hooks index; the data flow is a small U: conv_in -> 3 down levels (2 transformer blocks
+    each, average-pool + 1x1 conv between levels) -> mid block -> 3 up levels (nearest upsample + 1x1 conv + skip;
+    3 transformer blocks each, up_blocks[1] with a ResnetBlock2D in front of every block: resnets[1] is the one the
+    feature injection patches) -> conv_out.  The extra layers are created AFTER the base class's, so a FakeUNet and
+    a RunnableUNet built from the same seed share the hooks' 16 blocks."""
+
+    def __init__(self, dims=(32, 64, 128), heads=4, cross_dim=32, latent_ch=4):
+        super().__init__(dims=dims, heads=heads, cross_dim=cross_dim)
+        d0, d1, d2 = dims
+        self.conv_in = nn.Conv2d(latent_ch, d0, 3, padding=1)
+        self.time_proj = nn.Linear(1, 16)
+        self.down = nn.ModuleList([nn.Conv2d(d0, d1, 1), nn.Conv2d(d1, d2, 1), nn.Conv2d(d2, d2, 1)])
+        self.up = nn.ModuleList([nn.Conv2d(d1, d0, 1), nn.Conv2d(d2, d1, 1), nn.Conv2d(d2, d2, 1)])
+        self.conv_out = nn.Conv2d(d0, latent_ch, 3, padding=1)
+
+    @staticmethod
+    def _tokens(attn, h, enc):
+        B, C, H, W = h.shape
+        tok = attn(h.flatten(2).transpose(1, 2), encoder_hidden_states=enc)
+        return tok.transpose(1, 2).reshape(B, C, H, W)
+
+    def forward(self, sample, t, encoder_hidden_states=None):
+        B = sample.shape[0]
+        temb = self.time_proj(torch.as_tensor(t, dtype=torch.float32, device=sample.device).reshape(1, 1) / 1000.0)
+        temb = temb.expand(B, -1)
+        h = self.conv_in(sample)
+        skips = []
+        for lvl in range(3):
+            for a in self.down_blocks[lvl].attentions:
+                h = self._tokens(a, h, encoder_hidden_states)
+            skips.append(h)
+            h = self.down[lvl](nn.functional.avg_pool2d(h, 2))
+        h = self._tokens(self.mid_block.attentions[0], h, encoder_hidden_states)
+        for res, lvl in ((1, 2), (2, 1), (3, 0)):
+            h = self.up[lvl](nn.functional.interpolate(h, scale_factor=2.0, mode="nearest")) + skips[lvl]
+            stage = self.up_blocks[res]
+            for i, a in enumerate(stage.attentions):
+                if len(stage.resnets):
+                    h = stage.resnets[i](h, temb)
+                h = self._tokens(a, h, encoder_hidden_states)
+        return {"sample": self.conv_out(h)}
+
+
+class FakeDDIMScheduler:
+    """What the driver uses of diffusers' DDIMScheduler: `timesteps` (a descending tensor) and
+    `step(noise_pred, t, x)['prev_sample']` (/root/reference/run_tokenflow_pnp.py:216, 246) -- the deterministic
+    (eta = 0) DDIM update on a 1000-step scaled-linear schedule."""
+
+    def __init__(self, n_steps, first=951):
+        betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.stride = 1000 // 20
+        self.timesteps = torch.tensor([first - self.stride * i for i in range(n_steps)])
+
+    def step(self, noise_pred, t, x):
+        t = int(t)
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[t - self.stride] if t - self.stride >= 0 else torch.tensor(1.0)
+        x0 = (x - (1 - a_t) ** 0.5 * noise_pred) / a_t ** 0.5
+        return {"prev_sample": a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * noise_pred}
