@@ -100,24 +100,49 @@ def test_restated_driver_equals_the_verbatim_cut(kind, tmp_path, monkeypatch):
             assert all(torch.equal(a, b) for a, b in zip(cv["blocks"], cr["blocks"]))
 
 
+def _tensor_compare(rec, ref, tol, what):
+    """`rec` against another full-tensor record of the same run shape: worst |difference| / range per kind."""
+    worst = dict(block=0.0, unet=0.0, x=0.0)
+    for s, g in zip(rec["steps"], ref["steps"]):
+        pairs = [("x", s["x"], g["x"])]
+        for c, gc_ in zip(s["calls"], g["calls"]):
+            assert torch.equal(c["indices"], gc_["indices"])
+            pairs += [("unet", c["unet"], gc_["unet"])] + [("block", a, b) for a, b in zip(c["blocks"], gc_["blocks"])]
+        for k, a, b in pairs:
+            worst[k] = max(worst[k], float((a - b).abs().max() / b.abs().max()))
+    assert max(worst.values()) <= tol, f"{what}: {worst} > {tol}"
+    return worst
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("model_autocast", [False, True])
 @pytest.mark.parametrize("kind", KINDS)
-def test_driver_over_hip_hooks_matches_reference_golden(kind, model_autocast, tmp_path):
-    """The driver methods over the HIP hook path on the GPU against the reference-generated golden.
+def test_driver_over_hip_hooks_matches_reference_golden(kind, model_autocast, tmp_path, monkeypatch):
+    """The driver methods over the HIP hook path on the GPU against the reference-generated golden: the hook-call
+    trace and the `pivotal_idx` draws exactly; every transformer block output of every UNet call, every noise
+    prediction and the latents after each step as fractions of the golden tensor's range:
 
-    model_autocast=False: the stand-in UNet's own layers stay fp32 (they run outside the decorator's autocast), so
-    the only 16-bit roundings are the kernels' (inputs of attention / NN search rounded to bf16): every block output,
-    the noise prediction and the latents within **1e-3 of range** of the fp32 reference run.
-    model_autocast=True: exactly what the decorator of `batched_denoise_step` asks for on a GPU (fp16 autocast of
-    every Linear / conv of the model, the reference's own operating mode); the fp16 roundings of
-    the model's layers now dominate: bound 1e-2 of range, the trace and the draws still exact.
+    model_autocast=False -- the stand-in UNet's own layers stay fp32 (they run outside the decorator's autocast), so
+      the only 16-bit roundings are the kernels' boundary: fp32 q / k / v / pivots rounded to bf16, bf16 attention
+      output.  (a) against the SAME driver run on the CPU over the oracle-backed ops with that rounding contract
+      (`FakeOps(round16=True)`): **1e-3 of range** -- the kernels' own error, carried through three denoising steps;
+      (b) against the pure-fp32 golden: 5e-3 of range -- the bf16 boundary itself (the CPU emulation of the contract
+      sits at 2.3e-3 of range per block, 1.3e-3 on the noise prediction: a bf16 half-ulp is 2e-3 of a value).
+    model_autocast=True -- exactly what the decorator of `batched_denoise_step` asks for on a GPU: fp16 autocast of
+      every Linear / conv of the model (the reference's operating mode); the kernels then compute
+      in f16.  Bound against the fp32 golden: 1e-2 of range (fp16 layers over three steps).
     """
     gold = load_golden("driver.pt")[kind]
     log = []
     methods, which = _methods(kind, log)
     rec = _run(kind, methods, tmp_path, device="cuda", model_autocast=model_autocast, keep_tensors=True)
     assert log == gold["trace"], f"hook-call trace differs from the reference driver's ({which} driver)"
-    tol = 1e-2 if model_autocast else 1e-3
+    tol = 1e-2 if model_autocast else 5e-3
     worst = _compare(rec, gold, tol, tol, tol, f"{kind}/{which}/autocast={model_autocast}")
-    print(f"driver seam gpu {kind} ({which}, model autocast {model_autocast}): worst fraction of range {worst}")
+    print(f"driver seam gpu {kind} ({which}, model autocast {model_autocast}) vs fp32 golden: worst fraction of "
+          f"range {worst}")
+    if not model_autocast:
+        monkeypatch.setattr(hooks, "ops", FakeOps(round16=True))
+        emu = _run(kind, _methods(kind, [])[0], tmp_path, keep_tensors=True)
+        w2 = _tensor_compare(rec, emu, 1e-3, f"{kind} vs rounding-matched CPU run")
+        print(f"driver seam gpu {kind} vs rounding-matched CPU hooks: worst fraction of range {w2}")
