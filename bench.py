@@ -19,8 +19,10 @@ config_pnp.yaml:21); the two states are also timed separately (`ms_per_step_inje
 N > 1: frames are sharded over ranks (tokenflow_amd/sharded.py): the SAME video is split, so scaling is "strong";
 the pivotal-pass exchange (frames <-> heads all-to-all or the single-collective bank all-gather, chosen per block;
 --pivotal-exchange forces one) and the neighbour halo exchange run through torch.distributed (RCCL) inside the
-timed region.  `value` / `ms_per_step` time the form whose results equal the single-GPU run bit for bit; the split
-form of the rank's attention is timed in a second region and reported as `ms_per_step_split`.  The step then follows the reference's call order: the pivotal pass over all 16 blocks, then the
+timed region.  Two forms of the rank's attention are timed in two regions of K steps each: the one-pass form, whose
+results equal the single-GPU run bit for bit (`ms_per_step_bit_identical`), and the split form (`ms_per_step_split`:
+small grids split the key sequence and merge in fp32; held to the oracle's bound like every other launch).  `value` /
+`ms_per_step` report the faster of the two and `value_form` names it.  The step then follows the reference's call order: the pivotal pass over all 16 blocks, then the
 propagation of all blocks (the halo of a block travels under the rest of the pivotal pass).
 
 Prints ONE JSON line (rank 0):
@@ -96,6 +98,9 @@ def parse():
                     help="run ONLY the cpu_baseline leg and print it (no GPU needed): with the reference tree mounted "
                          "($TOKENFLOW_REFERENCE, default /root/reference) this times the verbatim reference hooks "
                          "(kind = 'reference'), else the oracle port")
+    ap.add_argument("--input-sets", type=int, default=0,
+                    help="distinct synthetic input sets the steps cycle through (SURVEY 8d: inputs of step s, block b come "
+                         "from manual_seed(1234 + 16 s + b)); 0 = auto: one per step, at most 8, at most 64 GB in total")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-yardstick", action="store_true")
     ap.add_argument("--cpu-sample-levels", default="0,1,2,3")
@@ -375,6 +380,9 @@ def cpu_baseline(cfg, levels):
         t_spent += t_frame + t_nn2 + t_gb2
         parts.append(f"L{lvl}: attn frame {t_frame:.2f}s nn {t_nn2:.2f}s gather {t_gb2:.2f}s")
     return dict(value=cfg.frames / total, unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample_seconds=round(t_spent, 2), step_seconds_extrapolated=round(total, 1),
+                extrapolation="per level: one query frame of the attention, one 2-keyframe chunk of the search and of the "
+                              "gather, scaled by frames / chunks / blocks",
                 sample=("oracle (fp32 torch CPU restatement of the reference hooks; attention = "
                         "oracle.ext_attn_core_bmm, the reference's per-head bmm/softmax/bmm) timed per level on one "
                         "query frame (all heads, source + two bank problems), one 2-keyframe NN-search chunk and "
@@ -441,6 +449,8 @@ def cpu_baseline_reference(cfg, levels, full_l0=False):
         total += nblk * (t_attn + (C - 0.5) * t_chunk)
         parts.append(f"L{lvl}: {note}, chunk pass {t_chunk:.2f}s")
     return dict(value=cfg.frames / total, unit="frames/s", cores=torch.get_num_threads(), kind="reference",
+                sample_seconds=round(t_spent, 2), step_seconds_extrapolated=round(total, 1),
+                extrapolated_levels=[] if full_l0 else [l for l in levels if l == 0],
                 sample=("VERBATIM reference hooks (tokenflow_utils.py of omerbt/TokenFlow through oracle/ref_loader.py; fp32 "
                         "torch CPU): per level one block -- sa_forward on the whole 3K-frame batch and one two-keyframe chunk "
                         "pass of TokenFlowBlock.forward -- scaled by blocks and chunks to a full step "
@@ -456,6 +466,8 @@ def parity_check(cfg, blocks, w):
     by_level, f16_levels, attn_rows, nn_total = [], [], 0, 0
     worst_state, worst_state32, worst_ratio = {}, {}, [0.0]
     nn_bad = nn_diff = 0
+    iid_bad = iid_diff = iid_total = 0
+    within_half_ulp = True      # every sampled 16-bit output within 1e-3 + half an ulp of its reference value
     K, n = cfg.K, cfg.chunk
     for lvl in range(len(cfg.levels)):
         cands = [b for b in blocks if b.lvl == lvl]
@@ -486,6 +498,10 @@ def parity_check(cfg, blocks, w):
                     ref = pm @ vv                                                    # tokenflow_utils.py:173-179
                     e16 = (out[b, f, rows, head] - ref).abs()
                     err = max(err, float(e16.max()))
+                    # what ANY tensor of this 16-bit type holding `ref` is off by at worst: half an ulp
+                    half_ulp = torch.exp2(torch.floor(torch.log2(ref.abs().clamp_min(1e-30)))
+                                          - (8 if dt == torch.bfloat16 else 11))
+                    within_half_ulp = within_half_ulp and bool((e16 <= 1e-3 + half_ulp).all())
                     err32 = max(err32, float((out32[b, f, rows, head] - ref).abs().max()))
                     if dt == torch.bfloat16:
                         # the bound the parity tests assert for 16-bit P and output (tests/test_kernels_gpu.py)
@@ -521,18 +537,39 @@ def parity_check(cfg, blocks, w):
             n_bad += b_
         total = len(ids) * len(sample)
         nn_bad, nn_diff, nn_total = nn_bad + n_bad, nn_diff + n_diff, nn_total + total
+        # flavour (i) of SURVEY 8(d): iid LayerNorm(N(0,1)) targets -- the near-tie worst case of the argmax
+        gi = torch.Generator(device=tgt.device).manual_seed(4321 + lvl)
+        tgt_iid = torch.nn.functional.layer_norm(torch.randn(nS, D, generator=gi, device=tgt.device), (D,)).to(tgt.dtype)
+        idx_i = ops.nn_search(tgt_iid, blk.pivots, inv, ids).cpu()
+        sim_i = orc.batch_cosine_sim(tgt_iid[sample.to(tgt.device)].float().cpu(),
+                                     blk.pivots[ids].float().cpu().reshape(-1, D))
+        i_diff = i_bad = 0
+        for p_, s_ in enumerate(sim_i.chunk(len(ids), dim=1)):
+            a, b_ = orc.nn_mismatch_tie_aware(s_, s_.argmax(-1), idx_i[p_][sample], 1e-5)
+            i_diff += a
+            i_bad += b_
+        iid_bad, iid_diff, iid_total = iid_bad + i_bad, iid_diff + i_diff, iid_total + total
         by_level.append({"level": lvl, "S": S, "D": D, "head_dim": d,
                          "attn_linf": {k: round(v, 6) for k, v in worst.items()},
                          "attn_linf_fp32_out": {k: round(v, 6) for k, v in worst32.items()},
                          "attn_err_over_bf16_bound": round(lvl_ratio, 4),
                          "bf16_half_ulp_of_largest_ref": round(floor16, 6),
-                         "nn_mismatch_rate": n_bad / total, "nn_index_diff_rate": n_diff / total})
-    return {"attn_linf": round(max(worst_state.values()), 6),
+                         "nn_mismatch_rate": n_bad / total, "nn_index_diff_rate": n_diff / total,
+                         "nn_mismatch_rate_iid": i_bad / total, "nn_index_diff_rate_iid": i_diff / total})
+    linf32 = max(worst_state32.values())
+    return {"tolerance": 1e-3,
+            "attn_linf_fp32_out": round(linf32, 6),
+            "attn_fp32_out_within_tolerance": bool(linf32 < 1e-3),
+            "attn_16bit_within_half_ulp": within_half_ulp,
+            "attn_linf_16bit_out": round(max(worst_state.values()), 6),
+            "attn_linf": round(max(worst_state.values()), 6),
             "attn_linf_by_state": {k: round(v, 6) for k, v in worst_state.items()},
-            "attn_linf_fp32_out": round(max(worst_state32.values()), 6),
             "attn_err_over_bf16_bound": round(worst_ratio[0], 4),
-            "attn_rows_checked": attn_rows, "tolerance": 1e-3,
-            "tolerance_note": "attn_linf is absolute.  With P and the output in bf16 (8 significand bits; the reference's "
+            "attn_rows_checked": attn_rows,
+            "tolerance_note": "north_star's absolute 1e-3 is held by attn_linf_fp32_out (the normalised fp32 accumulator, "
+                              "TF_ATTN_OUT_F32) at every level; the 16-bit output tensor adds its own format rounding: "
+                              "attn_16bit_within_half_ulp = every sampled 16-bit output within 1e-3 + half an ulp of its "
+                              "reference value (what the parity tests assert).  attn_linf (= attn_linf_16bit_out) is absolute.  With P and the output in bf16 (8 significand bits; the reference's "
                               "autocast rounds at the same two points in its 16-bit type) the deviation is relative: "
                               "bound = 2e-4 + 2^-8 (|ref| + softmax.|V|), the one the parity tests assert; "
                               "attn_err_over_bf16_bound <= 1 means inside it.  attn_linf_fp32_out = the same launches with "
@@ -542,7 +579,12 @@ def parity_check(cfg, blocks, w):
                               "coarse levels is the rounding of the bf16 OUTPUT itself (half an ulp of |out| ~ 0.5-1: "
                               "bf16_half_ulp_of_largest_ref), which no bf16 tensor can avoid",
             "nn_mismatch_rate": nn_bad / nn_total, "nn_index_diff_rate": nn_diff / nn_total,
-            "nn_targets_checked": nn_total, "by_level": by_level,
+            "nn_mismatch_rate_iid": iid_bad / iid_total, "nn_index_diff_rate_iid": iid_diff / iid_total,
+            "nn_note": "nn_mismatch_rate = sampled (target, keyframe) pairs whose index differs from the fp32 oracle's by MORE "
+                       "than a near-tie (oracle similarity gap > 1e-5); nn_index_diff_rate = any difference.  Plain fields: "
+                       "video-like targets (permuted pivot rows + 0.1 noise, SURVEY 8d flavour ii); *_iid: independent "
+                       "LayerNorm(N(0,1)) targets (flavour i, the near-tie worst case)",
+            "nn_targets_checked": nn_total, "nn_targets_checked_iid": iid_total, "by_level": by_level,
             "f16": {"note": "the same problems with f16 inputs -- the reference's own autocast dtype (run_tokenflow_pnp.py:220): "
                             "P and the output carry 11 significand bits",
                     "attn_linf": round(max(l["attn_linf"] for l in f16_levels), 6),
@@ -633,8 +675,20 @@ def main():
     # second timed region (`ms_per_step_split`)
     shard = make_shard(False)
     shard_split = make_shard(True) if world > 1 and not args.no_attn_split else None
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    blocks = [Block(cfg, lvl, inj, shard, gen, dev) for lvl, inj in workload.BLOCKS]
+    # Inputs: step s, block b draw from manual_seed(1234 + 16 s + b) (+ a rank offset: every rank holds its
+    # own frames).  All sets are generated and resident in HBM BEFORE the timed region; step i runs on set i % n_sets, so
+    # no step re-reads what the previous one left in the 256 MB Infinity Cache (one set of cfg2 is ~1.1 GB).
+    def make_set(s_):
+        return [Block(cfg, lvl, inj, shard, torch.Generator(device=dev).manual_seed(1234 + 16 * s_ + b_ + 7919 * rank), dev)
+                for b_, (lvl, inj) in enumerate(workload.BLOCKS)]
+    m0 = torch.cuda.memory_allocated(dev)
+    input_sets = [make_set(0)]
+    set_bytes = max(torch.cuda.memory_allocated(dev) - m0, 1)
+    n_sets = args.input_sets if args.input_sets > 0 else max(1, min(args.steps, 8, int(64e9 // set_bytes)))
+    if n_sets > 1 and n_sets % 2:
+        n_sets -= 1          # even: the injection state (step parity) is then a function of the set index (graph keys)
+    input_sets += [make_set(s_) for s_ in range(1, n_sets)]
+    blocks = input_sets[0]
     w = blend_w(cfg.chunk, dev)
     exchange = None if args.pivotal_exchange == "auto" else args.pivotal_exchange
     names = {"heads": "frames<->heads all-to-all", "bank": "K/V bank all-gather (one collective)"}
@@ -650,7 +704,8 @@ def main():
         torch.cuda.synchronize()
 
     def step(i, events=None, sh=None):
-        return run_step(cfg, blocks, sh or shard, i % 2 == 0, w, events, exchange=exchange, per_chunk=args.per_chunk)
+        return run_step(cfg, input_sets[i % n_sets], sh or shard, i % 2 == 0, w, events, exchange=exchange,
+                        per_chunk=args.per_chunk)
 
     for i in range(args.warmup):
         step(i)
@@ -658,8 +713,8 @@ def main():
     if use_graph:
         from tokenflow_amd.graphs import GraphCache
         graphs = GraphCache(warmup=0)
-        for i in range(2):          # capture both injection states before the timed region
-            graphs.run(("step", i % 2), lambda i=i: step(i))
+        for i in range(max(2, n_sets)):   # capture every (input set, injection state) before the timed region
+            graphs.run(("step", i % max(2, n_sets)), lambda i=i: step(i))
     events, marks = [], []
     barrier()
     t0 = time.perf_counter()
@@ -668,7 +723,7 @@ def main():
         m.record()
         marks.append(m)
         if use_graph:
-            graphs.run(("step", i % 2), None)
+            graphs.run(("step", i % max(2, n_sets)), None)
         else:
             step(i, events)
     m = torch.cuda.Event(enable_timing=True)
@@ -698,8 +753,15 @@ def main():
             step(i, events)
         torch.cuda.synchronize()
 
-    ms_per_step = elapsed / args.steps * 1e3
-    value = cfg.frames * args.steps / elapsed
+    ms_bit = elapsed / args.steps * 1e3
+    # N > 1: `value` is the FASTEST form whose results are verified against the oracle (both are: the one-pass form
+    # through its bit-identity with the single-GPU kernels, the split form directly, tests/test_sharded_gpu.py);
+    # north_star asks for tolerance parity, not bit-identity across world sizes.  Both timings stay in the line.
+    value_form = "one-pass rank attention (bit-identical to the 1-GPU result)"
+    ms_per_step = ms_bit
+    if ms_split is not None and ms_split < ms_bit:
+        ms_per_step, value_form = ms_split, "split rank attention (key runs merged in fp32; held to the oracle's bound)"
+    value = cfg.frames / (ms_per_step * 1e-3)
     fa, fn, gb = workload.step_work(cfg)
     per_state = {True: [], False: []}
     for i in range(args.steps):
@@ -751,7 +813,11 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic",
+        "input_sets": {"n": n_sets, "gb_per_set": round(set_bytes / 1e9, 2),
+                       "note": "step i runs on set i % n; set s, block b seeded 1234 + 16 s + b; all resident before the timed region"},
         "ms_per_step_split": ms_split and round(ms_split, 3),
+        "ms_per_step_bit_identical": round(ms_bit, 3) if world > 1 else None,
+        "value_form": value_form if world > 1 else "single GPU",
         "ms_per_step_inject_on": avg(per_state[True]) and round(avg(per_state[True]), 3),
         "ms_per_step_inject_off": avg(per_state[False]) and round(avg(per_state[False]), 3),
         "config": {"workload": cfg.name + " (hot path: 16 blocks x [ext-attn + NN-search + gather/blend over %d chunks])" % cfg.K,
@@ -764,7 +830,7 @@ def main():
                    "frames sharded over %d GPUs; pivotal pass: %s%s; rank attention %s" % (
                        world, exch_name, ("; one library call per block (tf_rank_pivotal)" if args.backend == "native" else
                                          "; exchanges through the C ABI (tf_comm_*)") if hip_comm is not None else "",
-                       "bit-identical to 1 GPU (ms_per_step); ms_per_step_split = small grids split the key sequence and "
+                       "bit-identical to 1 GPU (ms_per_step_bit_identical); ms_per_step_split = small grids split the key sequence and "
                        "merge (equal within the output rounding)" if shard_split is not None
                        else "bit-identical to 1 GPU"),
                    "step_algorithmic_tflop": round((fa + fn) / 1e12, 2),

@@ -379,7 +379,7 @@ TF_API int tf_sendrecv_pivot(tf_comm* comm, const void* const* send, const int64
  * for the rank's keyframes against the bank of all K).  Rank r of W owns a contiguous run of the K keyframes (the
  * first K % W ranks one more); per block it
  *   TF_RANK_HEADS  packs head group w of its keyframes' q / k / v for every rank w (tf_head_pack), exchanges them
- *                  (tf_all_to_all_rows), computes the source branch of its own frames meanwhile,
+ *                  (tf_all_to_all_rows), computes the source branch of its own frames and
  *                  the uncond / cond branches of ITS head group over all K frames in place on the received buffer
  *                  (tf_ext_attn_fwd_strided, TF_ATTN_BANK_ONLY), sends the outputs back and unpacks them
  *                  (tf_head_unpack); needs H % W == 0 and one token stride for q, k, v;
@@ -399,7 +399,8 @@ TF_API int tf_sendrecv_pivot(tf_comm* comm, const void* const* send, const int64
  *               `stream` behind it (call it before the propagation reads slot 0; no host blocking)
  *   ws        : tf_rank_pivotal_workspace_bytes; holds the exchange buffers, so ONE workspace serves consecutive
  *               blocks of one stream (each use is complete before the next block touches it), not concurrent ones.
- * tf_rank_create makes two streams (exchange, halo) and the events on the CURRENT device; `comm` may be NULL (one rank: plain
+ * Every collective of `comm` is issued on the caller's stream (one communicator, one stream).
+ * tf_rank_create makes one stream (the halo's) and the events on the CURRENT device; `comm` may be NULL (one rank: plain
  * tf_ext_attn_fwd into kfo_ext), `halo_comm` NULL = comm (a second communicator lets the halo of block b travel
  * beside the exchanges of block b+1: collectives of one RCCL communicator execute in issue order).
  * ------------------------------------------------------------------------ */

@@ -145,6 +145,69 @@ def test_nn_search_cfg4_level0_planted_and_sampled():
     assert bad == 0
 
 
+def _iid(K, n, S, D, g):
+    """SURVEY 8(d) flavour (i): pivots AND targets are LayerNorm(N(0,1)) rows, independent -- the worst case for an
+    argmax (the best and the second-best pivot of a target are a few 1e-3 apart, near-ties at the 1e-6 level occur)."""
+    ln = torch.nn.functional.layer_norm
+    piv = ln(torch.randn(K, S, D, generator=g, device="cuda"), (D,)).bfloat16()
+    tgt = ln(torch.randn(n * S, D, generator=g, device="cuda"), (D,)).bfloat16()
+    return piv, tgt
+
+
+def _iid_rates(idx, tgt, piv, ids, rows=None):
+    """(targets checked, raw index-diff count, beyond-tie count at tau = 1e-5) against the fp32 oracle
+    (util.py:61-69 + the argmax of tokenflow_utils.py:335-343), per keyframe of `ids`."""
+    total = diff = bad = 0
+    t = tgt.float().cpu() if rows is None else tgt[rows.cuda()].float().cpu()
+    for p_, kf in enumerate(ids):
+        sim = orc.batch_cosine_sim(t, piv[kf].float().cpu())
+        got = idx[p_] if rows is None else idx[p_][rows]
+        a, b = orc.nn_mismatch_tie_aware(sim, sim.argmax(-1), got, 1e-5)
+        total, diff, bad = total + sim.shape[0], diff + a, bad + b
+    return total, diff, bad
+
+
+def test_nn_search_cfg2_level0_iid_full_oracle():
+    """The iid flavour at FULL size: one cfg2 level-0 chunk, 20 480 targets x 2 keyframes x 4 096 pivots, D = 320,
+    every target against the fp32 oracle.  An accumulation-order difference between the MFMA contraction and torch's
+    fp32 matmul may flip an argmax only inside a near-tie: beyond-tie rate (oracle similarity gap > 1e-5) must be 0;
+    the raw index-diff rate is printed (the bench reports it as `nn_index_diff_rate_iid`)."""
+    ops = _ops()
+    K, n, S, D, c = 8, 5, 4096, 320, 3
+    piv, tgt = _iid(K, n, S, D, torch.Generator(device="cuda").manual_seed(21))
+    idx = ops.nn_search(tgt, piv, ops.pivot_inv_norm(piv), [c, c - 1]).cpu()
+    total, diff, bad = _iid_rates(idx, tgt, piv, [c, c - 1])
+    print(f"cfg2 L0 iid: {total} (target, keyframe) pairs, index differs on {diff} ({diff / total:.2e}), beyond tie {bad}")
+    assert total == 2 * n * S and bad == 0
+    assert diff <= 1e-3 * total
+
+
+def test_nn_search_cfg4_level0_iid_sampled_rows():
+    """cfg4 level 0 (S = 9 216, n = 8: 73 728 targets per chunk), iid flavour, 4 096 sampled targets x 2 keyframes
+    against the fp32 oracle."""
+    ops = _ops()
+    K, n, S, D, c = 3, 8, 9216, 320, 2
+    piv, tgt = _iid(K, n, S, D, torch.Generator(device="cuda").manual_seed(23))
+    idx = ops.nn_search(tgt, piv, ops.pivot_inv_norm(piv), [c, c - 1]).cpu()
+    rows = torch.randperm(n * S, generator=torch.Generator().manual_seed(2))[:4096]
+    total, diff, bad = _iid_rates(idx, tgt, piv, [c, c - 1], rows)
+    print(f"cfg4 L0 iid: {total} pairs, index differs on {diff} ({diff / total:.2e}), beyond tie {bad}")
+    assert bad == 0 and diff <= 1e-3 * total
+
+
+@pytest.mark.parametrize("S,D", [(1024, 640), (256, 1280), (64, 1280)])
+def test_nn_search_coarse_levels_iid_full_oracle(S, D):
+    """The other kernels of the search family (D >= 640: LDS-staged panels; few workgroups: deep-contraction form) on
+    iid rows at the cfg2 sizes of levels 1-3, every target against the oracle."""
+    ops = _ops()
+    K, n, c = 8, 5, 5
+    piv, tgt = _iid(K, n, S, D, torch.Generator(device="cuda").manual_seed(S + D))
+    idx = ops.nn_search(tgt, piv, ops.pivot_inv_norm(piv), [c, c - 1]).cpu()
+    total, diff, bad = _iid_rates(idx, tgt, piv, [c, c - 1])
+    print(f"S={S} D={D} iid: {total} pairs, index differs on {diff} ({diff / total:.2e}), beyond tie {bad}")
+    assert bad == 0 and diff <= 1e-3 * total
+
+
 @pytest.mark.parametrize("P", [1, 2])
 def test_gather_blend_cfg2_level0_bit_exact(P):
     ops = _ops()

@@ -1708,9 +1708,18 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
 #endif
                                return launch_one<T, DH, 1, 4, MODE_DUAL, 3, false>(p, st);
                            },
-                           [&] { return il    ? launch_il<T, 40, 8, MODE_SOURCE, 4>(p, st)
-                                        : big ? launch_one<T, DH, 1, 8, MODE_SOURCE, 2, false>(p, st)
-                                              : launch_one<T, DH, 1, 4, MODE_SOURCE, 2, false>(p, st); });
+                           [&] {
+#ifndef TF_TUNE_NO_IL40_SRC4
+                               // a source-only call with fewer than 256 8-wave workgroups (a sharded rank's own frames:
+                               // 128 at cfg2 level 0) leaves half the CUs idle at 2 waves per SIMD; 4-wave workgroups
+                               // put one wave on every SIMD of the chip.  Same arithmetic per (query, head).
+                               if (il && (int64_t)p.Kq * ((p.S + 255) / 256) * p.H < 256)
+                                   return launch_il<T, 40, 4, MODE_SOURCE, 4>(p, st);
+#endif
+                               return il    ? launch_il<T, 40, 8, MODE_SOURCE, 4>(p, st)
+                                      : big ? launch_one<T, DH, 1, 8, MODE_SOURCE, 2, false>(p, st)
+                                            : launch_one<T, DH, 1, 4, MODE_SOURCE, 2, false>(p, st);
+                           });
         }
         return compose([&] { return big ? launch_one<T, DH, 1, 8, MODE_ALL, 2>(p, st)
                                         : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st); },
@@ -1718,6 +1727,19 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
                        [&] { return big ? launch_one<T, DH, 1, 8, MODE_SOURCE, 2>(p, st)
                                         : launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st); });
     } else if constexpr (DH == 64) {
+#ifdef TF_TUNE_IL64
+#ifndef TF_TUNE_IL64_NW
+#define TF_TUNE_IL64_NW 8
+#endif
+#ifndef TF_TUNE_IL64_MINW
+#define TF_TUNE_IL64_MINW 3
+#endif
+        const bool il = p.S % 64 == 0 && p.S >= 512;   // half-tile interleaved form (ext_attn_il_kernel)
+        if (il)
+            return compose([&] { return launch_il<T, DH, TF_TUNE_IL64_NW, MODE_ALL, TF_TUNE_IL64_MINW>(p, st); },
+                           [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st); },
+                           [&] { return launch_il<T, DH, TF_TUNE_IL64_NW, MODE_SOURCE, TF_TUNE_IL64_MINW>(p, st); });
+#endif
         return compose([&] { return (p.S >= 512 && p.nseg == 1) ? launch_pp<T, DH, MODE_ALL, 2>(p, st)   // ping-pong: +8..11 %
                                                : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st); },
                        [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st); },

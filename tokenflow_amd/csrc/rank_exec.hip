@@ -7,13 +7,12 @@
 // and a Python host spends 200-300 us per block issuing them (profiles/r03_rank_step_v2.txt) -- more than the GPU
 // needs for the block at three of the four UNet levels.  Here the host cost is one foreign call.
 //
-// Streams: the caller's stream carries the compute; the frames<->heads / bank exchanges run on an exchange stream,
-// the neighbour halo on a halo stream (with its own communicator when the host gives one: collectives of ONE RCCL
-// communicator execute in issue order, and a 10 MB halo message in front of the next block's all-to-all would sit on
-// the critical path).  The source-branch attention stays on the caller's stream, between the issue of the first
-// exchange and the wait for it (an auxiliary compute stream for it was measured on the Python path: no gain at the
-// coarse levels, -4 % at level 0 where its workgroups take slots from the chip-filling bank grid).  All ordering is by
-// events; no host synchronisation anywhere.
+// Streams: the caller's stream carries the compute AND every collective of the pivotal pass's communicator (one
+// communicator, one stream: no reliance on cross-stream ordering inside RCCL; a hand-over between two streams also
+// costs ~10 us of idle device each way, profiles/r04_rank_timeline_v1.txt).  Only the neighbour halo has a stream of
+// its own (with its own communicator when the host gives one: collectives of ONE RCCL communicator execute in issue
+// order, and a 10 MB halo message in front of the next block's all-to-all would sit on the critical path); it has the
+// rest of the pass to arrive.  All ordering is by events; no host synchronisation anywhere.
 #include <new>
 
 #include "attn_fused.h"
@@ -44,7 +43,7 @@ struct tf_rank {
     tf_comm* halo_comm;
     int K, world, rank, Kl, kf0;
     int counts[TF_MAX_WORLD];
-    hipStream_t xs = nullptr, hs = nullptr;   // exchange, halo
+    hipStream_t hs = nullptr;   // neighbour halo
     hipEvent_t ring[RING];
     int ring_i = 0;
     hipEvent_t halo_done[TF_RANK_SLOTS];
@@ -132,7 +131,6 @@ extern "C" int tf_rank_create(tf_comm* comm, tf_comm* halo_comm, int K, tf_rank*
     for (int i = 0; i < RING && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&rk->ring[i], hipEventDisableTiming);
     for (int i = 0; i < TF_RANK_SLOTS && e == hipSuccess; ++i)
         e = hipEventCreateWithFlags(&rk->halo_done[i], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&rk->xs, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&rk->hs, hipStreamNonBlocking);
     if (e != hipSuccess) {
         tf_rank_destroy(rk);
@@ -144,7 +142,7 @@ extern "C" int tf_rank_create(tf_comm* comm, tf_comm* halo_comm, int K, tf_rank*
 
 extern "C" int tf_rank_destroy(tf_rank* rk) {
     if (!rk) return 0;
-    for (hipStream_t s : {rk->xs, rk->hs})
+    for (hipStream_t s : {rk->hs})
         if (s) {
             (void)hipStreamSynchronize(s);
             (void)hipStreamDestroy(s);
@@ -268,31 +266,35 @@ extern "C" int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const 
         sets[1].H = H, sets[1].Kq = Kl, sets[1].q_frame0 = 0, sets[1].Kb = Kl, sets[1].b0 = 0, sets[1].nb = 1;
         // small problems (the coarse levels, a rank's share of the middle ones): ONE launch for both sets behind the
         // exchange -- no V^T pre-passes, no split + merge pair, no separate source launch (csrc/ext_attn_fused.hip)
-        const TfFusedPlan plan = tf_attn_fused_plan(sets, 2, S, Dh, dtype, flags);
+        // The plan (which kernel, which key split: it decides the arithmetic) must be the SAME on every rank of the
+        // block: derived from rank-independent quantities -- the largest local run ceil(K / W) stands for Kl (with an
+        // uneven K the ranks' own Kl differ by one).
+        TfAttnSet plan_sets[2] = {sets[0], sets[1]};
+        plan_sets[1].Kq = plan_sets[1].Kb = (K + W - 1) / W;
+        const TfFusedPlan plan = tf_attn_fused_plan(plan_sets, 2, S, Dh, dtype, flags);
+        // Everything on the caller's stream, collectives included: every collective of the communicator is issued on
+        // ONE stream (no reliance on RCCL's ordering of one communicator across streams), and a hand-over between two
+        // streams costs ~10 us of idle device each way (profiles/r04_rank_timeline_v1.txt: four of them per block were
+        // 45 us of a 120 us block at the coarse levels).  Up to round 4 the level-0 form kept the first exchange on a
+        // side stream so that the source branch ran under the wire; that is ~40 us of wire per level-0 block left
+        // exposed now (estimated: no multi-GPU node to measure it), against two cross-stream dependencies removed.
+        if (const int rc = tf_all_to_all_rows(rk->comm, send, recv, own, cnt, ns * Shd, dtype, st)) return rc;
         if (plan.use) {
-            // Everything on the caller's stream: there is nothing to run beside the first exchange any more, and a
-            // hand-over between two streams costs ~10 us of idle device each way (profiles/r04_rank_timeline_v1.txt:
-            // four of them per block were 45 us of a 120 us block at the coarse levels).
-            if (const int rc = tf_all_to_all_rows(rk->comm, send, recv, own, cnt, ns * Shd, dtype, st)) return rc;
+            // small problems (the coarse levels, a rank's share of the middle ones): ONE launch for both sets behind
+            // the exchange -- no V^T pre-passes, no split + merge pair, no separate source launch
             if (const int rc = tf_attn_fused_launch(sets, 2, S, Dh, scale, flags, dtype, plan, st)) return rc;
         } else {
-            // ---- first all-to-all on the exchange stream and, under it, the source branch of the local frames
-            if (const int rc = order(rk, st, rk->xs, "tf_rank_pivotal")) return rc;
-            if (const int rc = tf_all_to_all_rows(rk->comm, send, recv, own, cnt, ns * Shd, dtype, rk->xs)) return rc;
-            hipEvent_t arrived = rk->next();
-            TF_HIP(hipEventRecord(arrived, rk->xs), "tf_rank_pivotal");
-            {
+            {   // the source branch of the local frames (independent of the exchange; issued behind it)
                 const int64_t strides[9] = {q_bs, q_fs, k_bs, k_fs, v_bs, v_fs, o_bs, SD, ld_q};
                 if (const int rc = tf_ext_attn_fwd_strided(q, k, v, out_loc, Kl, Kl, 0, S, H, Dh, ld, strides, scale,
-                                                           flags | TF_ATTN_SOURCE_ONLY, dtype, wsb + L.ws_src,
-                                                           L.ws_src_bytes, stream))
+                                                           flags | TF_ATTN_SOURCE_ONLY, dtype,
+                                                           wsb + L.ws_src, L.ws_src_bytes, stream))
                     return rc;
             }
-            TF_HIP(hipStreamWaitEvent(st, arrived, 0), "tf_rank_pivotal");
             const int64_t strides[9] = {Shd, fs_r, Shd, fs_r, Shd, fs_r, Shd, 2 * Shd, hd};
             if (const int rc = tf_ext_attn_fwd_strided(qb, kb, vb, ob, K, K, 0, S, Hl, Dh, hd, strides, scale,
-                                                       flags | TF_ATTN_BANK_ONLY, dtype, wsb + L.ws_bank, L.ws_bank_bytes,
-                                                       stream))
+                                                       flags | TF_ATTN_BANK_ONLY, dtype,
+                                                       wsb + L.ws_bank, L.ws_bank_bytes, stream))
                 return rc;
         }
         // ---- outputs back to the frame owners: on the caller's stream (nothing can run beside this exchange: the

@@ -9,6 +9,17 @@ mkdir -p "$O"
 for stage in "$@"; do
   echo "=== stage $stage $(date +%T)"
   case $stage in
+    seam)       timeout 900 python -m pytest tests/test_driver_seam.py tests/test_fullsize_gpu.py -m gpu -q --tb=short -p no:cacheprovider -s -k "driver or iid" 2>&1 | grep -v "^$" | tail -40 > $O/seam_tests.txt; grep -i "driver seam\|iid:\|passed\|failed\|Error\|assert" $O/seam_tests.txt | cut -c1-260 ;;
+    il64ab)     for lib in "" il64_4_3 il64_8_4 il64_8_3; do echo "== lib=${lib:-default}" | tee -a $O/attn_il64_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 10,9216,5,64 25,4096,5,64 10,2304,10,64 25,1024,10,64 2>/dev/null | tee -a $O/attn_il64_ab.txt; done
+                TOKENFLOW_HIP_LIB=build/variants/lib_il64_4_3.so timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_baseline_configs_gpu.py -q --tb=line -p no:cacheprovider -k "64 or cfg4 or cfg5" 2>&1 | tail -5 | tee -a $O/attn_il64_ab.txt ;;
+    nosplitab)  for ns in 0 1; do echo "== TOKENFLOW_ATTN_NO_SPLIT=$ns" | tee -a $O/attn_nosplit_ab.txt
+                  TOKENFLOW_ATTN_NO_SPLIT=$ns timeout 300 python tools/attn_microbench.py 8,256,8,160 8,64,8,160 4,256,8,80 4,64,8,160 10,144,20,64 2>/dev/null | tee -a $O/attn_nosplit_ab.txt; done ;;
+    pmc40)      # instruction-level accounting of the level-0 kernel (no ATT decoder in this image: SQ counters, separate passes)
+                for grp in "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES" "SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_THREAD_CYCLES_VALU" "SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32" "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_IFETCH" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VALU_INT32" "SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VALU2 SQ_BUSY_CU_CYCLES SQ_WAVES"; do
+                  rm -rf /tmp/p40; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/p40 -- python $GRAFT_REPO_ROOT/tools/attn_microbench.py 8,4096,8,40 > /dev/null 2>>$GRAFT_REPO_ROOT/$O/pmc40.err )
+                  DB=$(find /tmp/p40 -name "*_results.db" | head -1); [ -n "$DB" ] && python tools/rocpd_pmc.py $DB | grep "il_kernel<BF16; 40; 8; 0\|^kernel" >> $O/pmc_l0_accounting.csv; done
+                cut -c1-60,100-220 $O/pmc_l0_accounting.csv ;;
     trprobe)    timeout 60 tools/ubench/tr_probe > $O/tr_probe.txt 2>&1; cat $O/tr_probe.txt ;;
     fusedtests) timeout 900 python -m pytest tests/test_fused_attn_gpu.py -q --tb=line -p no:cacheprovider 2>&1 | tail -40 > $O/fused_tests.txt; tail -25 $O/fused_tests.txt ;;
     kerneltests) timeout 1500 python -m pytest tests/test_kernels_gpu.py -q --tb=line -p no:cacheprovider -k "attn" 2>&1 | tail -30 > $O/kernel_attn_tests.txt; tail -15 $O/kernel_attn_tests.txt ;;
