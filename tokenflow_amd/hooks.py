@@ -90,7 +90,8 @@ def register_frame_shard(diffusion_model, shard):
       * the chunk passes name GLOBAL chunk indices (`register_batch_idx(model, c)`, c owned by this rank; a run of the
         rank's chunks for the one-pass form) and read keyframes c and c-1 (tokenflow_utils.py:331-333) from the
         rank's halo-extended caches, the first one waiting for the neighbour's message.
-    Results equal the single-process hooks' bit for bit (`FrameShard`'s default one-pass attention); every rank must
+    Results equal the single-process hooks' in the bit-stable mode (TOKENFLOW_ATTN_NO_SPLIT=1) bit for bit (`FrameShard`'s
+    default one-pass attention; against the default single-process mode: within the attention's parity bound); every rank must
     draw the same `pivotal_idx` (run_tokenflow_pnp.py:224).  INTEGRATION.md section 3 shows the driver side."""
     for module in _tokenflow_blocks(diffusion_model):
         module.__dict__["_tf_shard"] = shard

@@ -41,9 +41,16 @@ def _launch(dev, what: str, fn, *args, stream: Optional[int] = None):
         _lib.check(rc, what)
 
 
+# 16-bit type fp32 tensors are rounded to at the op boundary (an fp32 model run WITHOUT autocast; under autocast the
+# projections already arrive in the autocast dtype).  bf16 (default) cannot overflow; TOKENFLOW_FP32_AS=f16 keeps 11
+# significand bits instead of 8 -- the reference's own GPU dtype (run_tokenflow_pnp.py:47, 220) -- for models whose
+# activations stay inside f16's range.
+FP32_AS = {"bf16": torch.bfloat16, "f16": torch.float16}[os.environ.get("TOKENFLOW_FP32_AS", "bf16")]
+
+
 def compute_dtype(t: torch.Tensor) -> torch.dtype:
-    """16-bit MFMA input type used for a tensor of dtype t.dtype (fp32 inputs are rounded to bf16)."""
-    return t.dtype if t.dtype in (torch.bfloat16, torch.float16) else torch.bfloat16
+    """16-bit MFMA input type used for a tensor of dtype t.dtype (fp32 inputs are rounded to `FP32_AS`)."""
+    return t.dtype if t.dtype in (torch.bfloat16, torch.float16) else FP32_AS
 
 
 _ws_cache = {}

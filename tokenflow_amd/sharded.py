@@ -44,13 +44,15 @@ pivotal pass of a block is ONE library call (tf_rank_pivotal, csrc/rank_exec.hip
 reaches them through `tokenflow_amd.hooks.register_frame_shard`.
 
 Work is partitioned, not re-associated: every output element is produced by exactly the same
-kernel arithmetic as on one GPU (the attention of one (query, head) visits the K frames in the
-same order, whoever computes it), so sharded results equal single-process results bit for bit.
-That is the default: `FrameShard` asks the attention for its one-pass form (TF_ATTN_NO_SPLIT),
-whose arithmetic does not depend on the grid.  `FrameShard(..., attn_split=True)` (or
-TOKENFLOW_SHARD_ATTN_SPLIT=1) lets the small grid of a rank split the bank over extra workgroups
-and merge: faster, and equal to the single-GPU result only within the output
-rounding, because the merge re-associates fp32 sums.
+kernel arithmetic as on one GPU IN THE BIT-STABLE MODE (the attention of one (query, head) visits the
+K frames in the same order, whoever computes it).  That is the default: `FrameShard` asks the attention
+for its one-pass form (TF_ATTN_NO_SPLIT), in which kernel choice and in-workgroup key split are functions
+of the shape alone; a sharded run then equals a single-GPU run with TOKENFLOW_ATTN_NO_SPLIT=1 (and a
+world-1 `FrameShard`) bit for bit.  The single-GPU DEFAULT mode is free to choose per grid (large grids of
+<= 256-token frames run without the key split: cfg2 level 2, +26 % faster there, profiles/r05_attn_nosplit_ab.txt)
+and agrees with the sharded results within the attention's parity bound, like any two correct launches.
+`FrameShard(..., attn_split=True)` (or TOKENFLOW_SHARD_ATTN_SPLIT=1) lets the small grid of a rank split
+the bank over extra workgroups and merge: faster, held to the ORACLE's bound.
 """
 import ctypes
 import os
@@ -302,9 +304,11 @@ class FrameShard:
         out4: a [3,Kl,S,D] view (dense frames, free branch stride) the result is written into in place -- the
         keyframe slots 1.. of a halo-extended buffer (`ext_alloc`); returned as is."""
         if self.world == 1:
+            # the same mode as a rank of a larger world: a world-1 shard equals a world-W shard bit for bit by default
+            ns = not self.attn_split
             if out4 is None:
-                return ops.ext_attn(q_local, k_local, v_local, heads, scale, inject)
-            return ops.ext_attn(q_local, k_local, v_local, heads, scale, inject, out=out4.view(q_local.shape))
+                return ops.ext_attn(q_local, k_local, v_local, heads, scale, inject, no_split=ns)
+            return ops.ext_attn(q_local, k_local, v_local, heads, scale, inject, out=out4.view(q_local.shape), no_split=ns)
         if mode is None:
             mode = self.auto_mode(heads, q_local.shape[1])
         if mode == "heads":

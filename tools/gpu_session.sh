@@ -20,6 +20,11 @@ for stage in "$@"; do
                   rm -rf /tmp/p40; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/p40 -- python $GRAFT_REPO_ROOT/tools/attn_microbench.py 8,4096,8,40 > /dev/null 2>>$GRAFT_REPO_ROOT/$O/pmc40.err )
                   DB=$(find /tmp/p40 -name "*_results.db" | head -1); [ -n "$DB" ] && python tools/rocpd_pmc.py $DB | grep "il_kernel<BF16; 40; 8; 0\|^kernel" >> $O/pmc_l0_accounting.csv; done
                 cut -c1-60,100-220 $O/pmc_l0_accounting.csv ;;
+    seam2)      timeout 900 python -m pytest tests/test_driver_seam.py tests/test_sharded_gpu.py -m gpu -q --tb=short -p no:cacheprovider -s -k "driver or shard_vs_default" 2>&1 | grep -v "^$" | tail -60 > $O/seam2_tests.txt; grep -ai "driver seam\|passed\|failed\|Error\|assert" $O/seam2_tests.txt | cut -c1-300 ;;
+    inputsab)   for n in 1 0 1 0; do timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-yardstick --no-parity --input-sets $n > $O/bench_sets_$n.json 2>> $O/inputsab.err; python -c "import json;d=json.load(open('$O/bench_sets_$n.json'));print('input sets',d['input_sets']['n'],d['ms_per_step'],d['ms_per_step_inject_on'],d['ms_per_step_inject_off'],d['roofline']['avg_launch_ms'])" | tee -a $O/input_sets_ab.txt; done ;;
+    src4ab)     for lib in "" nosrc4 "" nosrc4; do echo "== lib=${lib:-current}" | tee -a $O/rank_step_src4_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/rank_step_microbench.py --native --only split,auto --no-copies --reps 12 2>/dev/null | grep "step inject\|level 0" | tee -a $O/rank_step_src4_ab.txt; done ;;
+    bmmprobe)   timeout 300 python tools/bmm_out_probe.py > $O/bmm_out_probe.txt 2>&1; grep -v amdgpu.ids $O/bmm_out_probe.txt | cut -c1-330 ;;
     trprobe)    timeout 60 tools/ubench/tr_probe > $O/tr_probe.txt 2>&1; cat $O/tr_probe.txt ;;
     fusedtests) timeout 900 python -m pytest tests/test_fused_attn_gpu.py -q --tb=line -p no:cacheprovider 2>&1 | tail -40 > $O/fused_tests.txt; tail -25 $O/fused_tests.txt ;;
     kerneltests) timeout 1500 python -m pytest tests/test_kernels_gpu.py -q --tb=line -p no:cacheprovider -k "attn" 2>&1 | tail -30 > $O/kernel_attn_tests.txt; tail -15 $O/kernel_attn_tests.txt ;;
