@@ -33,6 +33,8 @@
 //   ext_attn_kernel<.., MODE_DUAL>               q/k injection: uncond + cond share QK^T and the softmax
 //   ext_attn_pp_kernel                           two query tiles per wave, softmax of one interleaved
 //                                                in program order with the MFMAs of the other
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "attn_fused.h"
@@ -763,6 +765,10 @@ static int split_plan(int K, int Kq, int S, int H, int Dh, bool inject, int part
     if (K * tpf < 16) return 1;   // a bank of a few tiles: the merge launch costs more than it buys (8x8 level)
     int nseg = 1;
     while (wgs * 4 * nseg < (int64_t)occ * 1024 && nseg * 2 <= K && (K / (nseg * 2)) * tpf >= 2) nseg *= 2;
+    // TOKENFLOW_SPLIT_OVER=n (experiments): n further doublings once the chip is full -- shorter workgroups, so that a
+    // launch running BESIDE this one (a rank's source branch on an auxiliary stream) is absorbed instead of appended
+    static const int over = [] { const char* e = getenv("TOKENFLOW_SPLIT_OVER"); return e ? atoi(e) : 0; }();
+    for (int i = 0; i < over && nseg > 1 && nseg * 2 <= K && (K / (nseg * 2)) * tpf >= 2; ++i) nseg *= 2;
     return nseg;
 }
 
@@ -1709,10 +1715,12 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
                                return launch_one<T, DH, 1, 4, MODE_DUAL, 3, false>(p, st);
                            },
                            [&] {
-#ifndef TF_TUNE_NO_IL40_SRC4
-                               // a source-only call with fewer than 256 8-wave workgroups (a sharded rank's own frames:
-                               // 128 at cfg2 level 0) leaves half the CUs idle at 2 waves per SIMD; 4-wave workgroups
-                               // put one wave on every SIMD of the chip.  Same arithmetic per (query, head).
+#ifdef TF_TUNE_IL40_SRC4
+                               // A/B switch, off: a source-only call with fewer than 256 8-wave workgroups (a sharded
+                               // rank's own frames: 128 at cfg2 level 0, 2 waves per SIMD on half the CUs) as 4-wave
+                               // workgroups on every CU (1 wave per SIMD) measured SLOWER, 98 vs 61 us per level-0 block
+                               // of a rank (profiles/r05_rank_step_src4_ab.txt): half the waves share each staged tile
+                               // and a lone wave per SIMD hides nothing.
                                if (il && (int64_t)p.Kq * ((p.S + 255) / 256) * p.H < 256)
                                    return launch_il<T, 40, 4, MODE_SOURCE, 4>(p, st);
 #endif

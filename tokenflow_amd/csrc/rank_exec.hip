@@ -13,6 +13,8 @@
 // its own (with its own communicator when the host gives one: collectives of ONE RCCL communicator execute in issue
 // order, and a 10 MB halo message in front of the next block's all-to-all would sit on the critical path); it has the
 // rest of the pass to arrive.  All ordering is by events; no host synchronisation anywhere.
+#include <stdlib.h>
+
 #include <new>
 
 #include "attn_fused.h"
@@ -44,6 +46,7 @@ struct tf_rank {
     int K, world, rank, Kl, kf0;
     int counts[TF_MAX_WORLD];
     hipStream_t hs = nullptr;   // neighbour halo
+    hipStream_t as = nullptr;   // auxiliary COMPUTE stream (TOKENFLOW_RANK_SRC_AUX: the source branch beside the bank launch)
     hipEvent_t ring[RING];
     int ring_i = 0;
     hipEvent_t halo_done[TF_RANK_SLOTS];
@@ -132,6 +135,7 @@ extern "C" int tf_rank_create(tf_comm* comm, tf_comm* halo_comm, int K, tf_rank*
     for (int i = 0; i < TF_RANK_SLOTS && e == hipSuccess; ++i)
         e = hipEventCreateWithFlags(&rk->halo_done[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&rk->hs, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&rk->as, hipStreamNonBlocking);
     if (e != hipSuccess) {
         tf_rank_destroy(rk);
         return hip_fail("tf_rank_create", e);
@@ -142,7 +146,7 @@ extern "C" int tf_rank_create(tf_comm* comm, tf_comm* halo_comm, int K, tf_rank*
 
 extern "C" int tf_rank_destroy(tf_rank* rk) {
     if (!rk) return 0;
-    for (hipStream_t s : {rk->hs})
+    for (hipStream_t s : {rk->hs, rk->as})
         if (s) {
             (void)hipStreamSynchronize(s);
             (void)hipStreamDestroy(s);
@@ -284,11 +288,16 @@ extern "C" int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const 
             // the exchange -- no V^T pre-passes, no split + merge pair, no separate source launch
             if (const int rc = tf_attn_fused_launch(sets, 2, S, Dh, scale, flags, dtype, plan, st)) return rc;
         } else {
-            {   // the source branch of the local frames (independent of the exchange; issued behind it)
+            // the source branch of the local frames (independent of the exchange).  TOKENFLOW_RANK_SRC_AUX=1 (experiment):
+            // on the auxiliary compute stream, beside the bank launch
+            static const bool src_aux = [] { const char* e = getenv("TOKENFLOW_RANK_SRC_AUX"); return e && atoi(e) != 0; }();
+            {
+                if (src_aux)
+                    if (const int rc = order(rk, st, rk->as, "tf_rank_pivotal")) return rc;
                 const int64_t strides[9] = {q_bs, q_fs, k_bs, k_fs, v_bs, v_fs, o_bs, SD, ld_q};
                 if (const int rc = tf_ext_attn_fwd_strided(q, k, v, out_loc, Kl, Kl, 0, S, H, Dh, ld, strides, scale,
                                                            flags | TF_ATTN_SOURCE_ONLY, dtype,
-                                                           wsb + L.ws_src, L.ws_src_bytes, stream))
+                                                           wsb + L.ws_src, L.ws_src_bytes, src_aux ? rk->as : st))
                     return rc;
             }
             const int64_t strides[9] = {Shd, fs_r, Shd, fs_r, Shd, fs_r, Shd, 2 * Shd, hd};
@@ -296,6 +305,8 @@ extern "C" int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const 
                                                        flags | TF_ATTN_BANK_ONLY, dtype,
                                                        wsb + L.ws_bank, L.ws_bank_bytes, stream))
                 return rc;
+            if (src_aux)
+                if (const int rc = order(rk, rk->as, st, "tf_rank_pivotal")) return rc;
         }
         // ---- outputs back to the frame owners: on the caller's stream (nothing can run beside this exchange: the
         //      unpack and the next block need its result)

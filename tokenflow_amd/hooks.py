@@ -513,8 +513,14 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
                     def dest(dt, _s=shard0):
                         nb, ib, _ = _shard_state(self, _s, sequence_length, dim, dt, hidden_states.device)
                         return nb[1:].view(3, n_frames, sequence_length, dim), ib[1:].view(3, n_frames, sequence_length)
-                norm_hidden_states, norm_inv = _block_norm(self.norm1, hidden_states, bool(self.pivotal_pass), dest=dest)
-            norm_hidden_states = norm_hidden_states.view(3, n_frames, sequence_length, dim)
+                if self.pivotal_pass:
+                    norm_hidden_states, norm_inv = _block_norm(self.norm1, hidden_states, True, dest=dest)
+                else:
+                    # a propagation pass reads norm1's output of the SOURCE branch only (the NN-search targets,
+                    # 335-343; the reference normalises all three branches at 323 and drops two): one third of the
+                    # launch's bytes.  Row-wise op: the rows that are computed are bit-identical.
+                    norm_hidden_states, norm_inv = _block_norm(self.norm1, hidden_states[:1])[0], None
+            norm_hidden_states = norm_hidden_states.view(-1, n_frames, sequence_length, dim)
 
             cross_attention_kwargs = cross_attention_kwargs if cross_attention_kwargs is not None else {}
             if self.pivotal_pass:

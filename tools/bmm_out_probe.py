@@ -5,6 +5,7 @@ attention-output state of a sharded rank, tokenflow_amd/hooks.py.)"""
 import torch
 
 dev = torch.device("cuda")
+torch.set_grad_enabled(False)
 for Kl, S, D in [(1, 4096, 320), (1, 1024, 640), (1, 256, 1280), (1, 64, 1280), (4, 4096, 320)]:
     for dt in (torch.bfloat16, torch.float16):
         x = torch.randn(3 * Kl, S, D, device=dev, dtype=dt)
