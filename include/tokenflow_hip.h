@@ -400,7 +400,7 @@ TF_API int tf_sendrecv_pivot(tf_comm* comm, const void* const* send, const int64
  *   ws        : tf_rank_pivotal_workspace_bytes; holds the exchange buffers, so ONE workspace serves consecutive
  *               blocks of one stream (each use is complete before the next block touches it), not concurrent ones.
  * Every collective of `comm` is issued on the caller's stream (one communicator, one stream).
- * tf_rank_create makes one stream (the halo's) and the events on the CURRENT device; `comm` may be NULL (one rank: plain
+ * tf_rank_create makes two streams (auxiliary compute, halo) and the events on the CURRENT device; `comm` may be NULL (one rank: plain
  * tf_ext_attn_fwd into kfo_ext), `halo_comm` NULL = comm (a second communicator lets the halo of block b travel
  * beside the exchanges of block b+1: collectives of one RCCL communicator execute in issue order).
  * ------------------------------------------------------------------------ */

@@ -1705,7 +1705,14 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
 #else
             const bool il = false;
 #endif
-            return compose([&] { return il    ? launch_il<T, 40, 8, MODE_ALL, 4>(p, st)
+            return compose([&] {
+#ifdef TF_TUNE_IL40_NW4_SMALL
+                               // A/B switch: fewer than two 8-wave workgroups per CU (a rank's one-pass level 0: 256) as
+                               // twice as many 4-wave workgroups -- two barrier groups per CU instead of one
+                               if (il && (int64_t)(p.part == TF_ATTN_BANK_ONLY ? 2 : 3) * p.Kq * ((p.S + 255) / 256) * p.H * p.nseg < 512)
+                                   return launch_il<T, 40, 4, MODE_ALL, 4>(p, st);
+#endif
+                               return il    ? launch_il<T, 40, 8, MODE_ALL, 4>(p, st)
                                         : big ? launch_one<T, DH, 1, 8, MODE_ALL, 2, false>(p, st)
                                               : launch_one<T, DH, 1, 4, MODE_ALL, 2, false>(p, st); },
                            [&] {

@@ -8,11 +8,14 @@
 // needs for the block at three of the four UNet levels.  Here the host cost is one foreign call.
 //
 // Streams: the caller's stream carries the compute AND every collective of the pivotal pass's communicator (one
-// communicator, one stream: no reliance on cross-stream ordering inside RCCL; a hand-over between two streams also
-// costs ~10 us of idle device each way, profiles/r04_rank_timeline_v1.txt).  Only the neighbour halo has a stream of
-// its own (with its own communicator when the host gives one: collectives of ONE RCCL communicator execute in issue
-// order, and a 10 MB halo message in front of the next block's all-to-all would sit on the critical path); it has the
-// rest of the pass to arrive.  All ordering is by events; no host synchronisation anywhere.
+// communicator, one stream: no reliance on cross-stream ordering inside RCCL; a hand-over between two streams on the
+// critical path also costs ~10 us of idle device each way, profiles/r04_rank_timeline_v1.txt).  Two side streams:
+// an auxiliary COMPUTE stream runs the source branch of the local frames beside the first exchange and the bank
+// attention where those are separate launches (level 0; forked and joined by events, nothing waits on it before the
+// join), and the neighbour halo has a stream of its own (with its own communicator when the host gives one:
+// collectives of ONE RCCL communicator execute in issue order, and a 10 MB halo message in front of the next block's
+// all-to-all would sit on the critical path); it has the rest of the pass to arrive.  All ordering is by events; no
+// host synchronisation anywhere.
 #include <stdlib.h>
 
 #include <new>
@@ -46,7 +49,7 @@ struct tf_rank {
     int K, world, rank, Kl, kf0;
     int counts[TF_MAX_WORLD];
     hipStream_t hs = nullptr;   // neighbour halo
-    hipStream_t as = nullptr;   // auxiliary COMPUTE stream (TOKENFLOW_RANK_SRC_AUX: the source branch beside the bank launch)
+    hipStream_t as = nullptr;   // auxiliary COMPUTE stream: the source branch beside the exchange and the bank launch
     hipEvent_t ring[RING];
     int ring_i = 0;
     hipEvent_t halo_done[TF_RANK_SLOTS];
@@ -288,9 +291,13 @@ extern "C" int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const 
             // the exchange -- no V^T pre-passes, no split + merge pair, no separate source launch
             if (const int rc = tf_attn_fused_launch(sets, 2, S, Dh, scale, flags, dtype, plan, st)) return rc;
         } else {
-            // the source branch of the local frames (independent of the exchange).  TOKENFLOW_RANK_SRC_AUX=1 (experiment):
-            // on the auxiliary compute stream, beside the bank launch
-            static const bool src_aux = [] { const char* e = getenv("TOKENFLOW_RANK_SRC_AUX"); return e && atoi(e) != 0; }();
+            // The source branch of the local frames (independent of the exchange) on the auxiliary COMPUTE stream, beside
+            // the exchange and the bank launch: a rank's own frames are too few workgroups to fill the chip (cfg2 level 0
+            // at W = 8: 128 workgroups, 61 us alone); beside the bank launch they are absorbed -- 471 -> 440 us per level-0
+            // block, 4.26 -> 4.08 ms per rank step with the wire taken out (profiles/r05_rank_step_srcaux_ab.txt) -- and on
+            // a real wire they run under the first exchange.  Collectives stay on the caller's stream.
+            // TOKENFLOW_RANK_SRC_AUX=0: in line on the caller's stream.
+            static const bool src_aux = [] { const char* e = getenv("TOKENFLOW_RANK_SRC_AUX"); return !e || atoi(e) != 0; }();
             {
                 if (src_aux)
                     if (const int rc = order(rk, st, rk->as, "tf_rank_pivotal")) return rc;

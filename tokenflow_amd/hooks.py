@@ -414,6 +414,9 @@ def _fused_norm_dtype(mod: torch.nn.Module, x: torch.Tensor, in_dtype=None):
 FUSE_NORMS = os.environ.get("TOKENFLOW_FUSED_NORMS", "all")
 # TOKENFLOW_FUSED_GATHER_NORM=0: keep the propagation's gather and the norm behind it as two launches
 FUSE_GATHER_NORM = os.environ.get("TOKENFLOW_FUSED_GATHER_NORM", "1") not in ("", "0")
+# TOKENFLOW_NORM1_ALL_BRANCHES=1: a propagation pass normalises all three branches as the reference does (323) although
+# only the source branch is read (335-343); default: the source branch alone (A/B: profiles/r05_hooks_bench.txt)
+NORM1_ALL_BRANCHES = os.environ.get("TOKENFLOW_NORM1_ALL_BRANCHES", "0") not in ("", "0")
 
 
 def _block_norm(mod: torch.nn.Module, x: torch.Tensor, want_inv_norm: bool = False, which: str = "norm1", dest=None):
@@ -513,8 +516,8 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
                     def dest(dt, _s=shard0):
                         nb, ib, _ = _shard_state(self, _s, sequence_length, dim, dt, hidden_states.device)
                         return nb[1:].view(3, n_frames, sequence_length, dim), ib[1:].view(3, n_frames, sequence_length)
-                if self.pivotal_pass:
-                    norm_hidden_states, norm_inv = _block_norm(self.norm1, hidden_states, True, dest=dest)
+                if self.pivotal_pass or NORM1_ALL_BRANCHES:
+                    norm_hidden_states, norm_inv = _block_norm(self.norm1, hidden_states, bool(self.pivotal_pass), dest=dest)
                 else:
                     # a propagation pass reads norm1's output of the SOURCE branch only (the NN-search targets,
                     # 335-343; the reference normalises all three branches at 323 and drops two): one third of the

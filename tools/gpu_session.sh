@@ -28,6 +28,9 @@ for stage in "$@"; do
     srcaux)     for e in "X=0" "TOKENFLOW_RANK_SRC_AUX=1" "TOKENFLOW_RANK_SRC_AUX=1 TOKENFLOW_SPLIT_OVER=1" "TOKENFLOW_SPLIT_OVER=1" "X=0" "TOKENFLOW_RANK_SRC_AUX=1 TOKENFLOW_SPLIT_OVER=1"; do echo "== env $e" | tee -a $O/rank_step_srcaux_ab.txt
                   env $e timeout 300 python tools/rank_step_microbench.py --native --only split,auto --no-copies --reps 12 2>/dev/null | grep "step inject\|level 0" | tee -a $O/rank_step_srcaux_ab.txt; done ;;
     hooks2)     for a in "6" "6 --graph" "10 --ranks 8 --wire-less --graph" "10 --ranks 8 --wire-less"; do timeout 600 python tools/hooks_bench.py cfg2 $a >> $O/hooks_bench2.txt 2>/dev/null; done; cat $O/hooks_bench2.txt ;;
+    hooksab)    for e in "TOKENFLOW_NORM1_ALL_BRANCHES=1" "TOKENFLOW_NORM1_ALL_BRANCHES=0" "TOKENFLOW_NORM1_ALL_BRANCHES=1" "TOKENFLOW_NORM1_ALL_BRANCHES=0"; do for a in "6 --graph" "10 --ranks 8 --wire-less --graph"; do echo -n "$e: " >> $O/hooks_norm1_ab.txt; env $e timeout 600 python tools/hooks_bench.py cfg2 $a >> $O/hooks_norm1_ab.txt 2>/dev/null; done; done; cat $O/hooks_norm1_ab.txt ;;
+    onepassab)  for lib in "" il40nw4 "" il40nw4; do echo "== lib=${lib:-current}" | tee -a $O/rank_step_onepass_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/rank_step_microbench.py --native --only onepass,auto --no-copies --reps 12 2>/dev/null | grep "step inject\|level 0" | tee -a $O/rank_step_onepass_ab.txt; done ;;
     trprobe)    timeout 60 tools/ubench/tr_probe > $O/tr_probe.txt 2>&1; cat $O/tr_probe.txt ;;
     fusedtests) timeout 900 python -m pytest tests/test_fused_attn_gpu.py -q --tb=line -p no:cacheprovider 2>&1 | tail -40 > $O/fused_tests.txt; tail -25 $O/fused_tests.txt ;;
     kerneltests) timeout 1500 python -m pytest tests/test_kernels_gpu.py -q --tb=line -p no:cacheprovider -k "attn" 2>&1 | tail -30 > $O/kernel_attn_tests.txt; tail -15 $O/kernel_attn_tests.txt ;;
