@@ -208,6 +208,40 @@ def test_nn_search_coarse_levels_iid_full_oracle(S, D):
     assert bad == 0 and diff <= 1e-3 * total
 
 
+@pytest.mark.parametrize("n,S,D,ids,flavour", [
+    (10, 1024, 640, [3, 2], "iid"),        # 40 panels x 2 keyframes x 4 pivot tiles
+    (9, 1020, 640, [1, 0], "iid"),         # ragged: last pivot tile 252 rows, last target panel 220 rows
+    (40, 512, 1280, [2, 1], "iid"),        # D = 1280: 20 D chunks per tile
+    (20, 1024, 640, [0], "videolike"),     # one keyframe (chunk 0 of a video), planted permutation
+    (3, 2304, 640, [1, 0], "iid"),         # cfg4 level 1 geometry: 9 pivot tiles
+])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_nn_search_lds_dma_kernel(n, S, D, ids, flavour, dtype):
+    """Shapes that take `nn_search_glds_kernel` (D % 64 == 0, D >= 512, chip-filling grid: the LDS-DMA staged
+    256 x 256 tiles), every target against the fp32 oracle, tie-aware; the video-like case also against its planted
+    permutation; one exact-duplicate pivot pair per keyframe: the first index must win (torch.argmax's rule)."""
+    ops = _ops()
+    K = max(ids) + 2
+    g = torch.Generator(device="cuda").manual_seed(n * S + D)
+    ln = torch.nn.functional.layer_norm
+    piv = ln(torch.randn(K, S, D, generator=g, device="cuda"), (D,)).to(dtype)
+    if flavour == "videolike":
+        perm = torch.stack([torch.randperm(S, generator=g, device="cuda") for _ in range(n)]).reshape(-1)
+        tgt = (piv[ids[0]].float()[perm] + 0.1 * torch.randn(n * S, D, generator=g, device="cuda")).to(dtype)
+    else:
+        tgt = ln(torch.randn(n * S, D, generator=g, device="cuda"), (D,)).to(dtype)
+        piv[:, S - 7] = piv[:, 5]          # exact duplicates: row 5 must win over row S - 7 wherever they are the maximum
+        tgt[:64] = piv[ids[0], 5].float().to(dtype)     # ... which they are for these targets
+    idx = ops.nn_search(tgt, piv, ops.pivot_inv_norm(piv), ids).cpu()
+    if flavour == "videolike":
+        assert torch.equal(idx[0].long(), perm.cpu())
+    else:
+        assert bool((idx[0][:64] == 5).all())
+    total, diff, bad = _iid_rates(idx, tgt, piv, ids)
+    print(f"n={n} S={S} D={D} {flavour} {str(dtype)[6:]}: {total} pairs, index differs on {diff}, beyond tie {bad}")
+    assert bad == 0 and diff <= 1e-3 * total
+
+
 @pytest.mark.parametrize("P", [1, 2])
 def test_gather_blend_cfg2_level0_bit_exact(P):
     ops = _ops()

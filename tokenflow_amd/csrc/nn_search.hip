@@ -274,6 +274,206 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
 }
 
 // ---------------------------------------------------------------------------
+// LDS-DMA variant for D % 64 == 0, D >= 512 (levels 1-2 of SD: D = 640, 1280) on grids that fill the chip.
+// The generic kernel above is LDS-bound there: a wave's 64 x 64 tile reads 4 fragments of 1 KB per 4 MFMAs and
+// re-stages (TM + TN) x BK per interval through registers -- 1.5 KB of LDS traffic per MFMA against the 1 KB the LDS
+// pipe (128 B/clk per CU) delivers in the 32 clocks an MFMA occupies one of the CU's four matrix pipes (counters:
+// profiles/r04_pmc_level1.csv).  Here a wave owns 64 pivots x 128 targets (6 fragment reads per 8 MFMAs) inside a
+// 256 x 256 workgroup tile of 8 waves (4 pivot quarters x 2 target halves): 0.75 + 0.25 KB per MFMA.  The 128
+// accumulator registers leave no room for two register staging sets (profiles/r04_nn_wide4_ab.txt: spills), so the
+// tiles go global -> LDS directly (`global_load_lds_dwordx4`: no staging registers, no ds_write pass).  The DMA
+// writes lane-linearly (wave-uniform base + lane * 16 B): the XOR swizzle of the image is applied on the SOURCE side
+// (the lane that fills slot s of row r fetches piece s ^ ((r >> 1) & 7) of that row) and on the read side, the same
+// involution (swz_off<64>).  Two LDS buffers; the DMA of chunk it+1 is issued before the MFMAs of chunk it and
+// drained (vmcnt(0)) in front of the interval's barrier.  The pivots' inverse norms of a tile arrive the same way.
+// Arithmetic per (target, pivot) and the first-index rule are those of nn_search_kernel.
+template <typename T>
+__global__ __launch_bounds__(512, 2) void nn_search_glds_kernel(const typename T::elem* __restrict__ tgt,
+                                                                const typename T::elem* __restrict__ piv,
+                                                                const float* __restrict__ inv_norm,
+                                                                int32_t* __restrict__ idx_out,
+                                                                NnPartial* __restrict__ part_out, int64_t n_tgt, int S,
+                                                                int D, int kf0, int kf1, int tiles_per_split, NnChunks ch) {
+    typedef typename T::vec8 vec8;
+    typedef typename T::elem E;
+    constexpr int TM = 256, TN = 256, BK = 64, NI = 2, WN = 4;
+    constexpr int A_BYTES = TM * BK * 2, B_BYTES = TN * BK * 2;   // 32 KB each
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    auto sA = [&](int b) { return smem + b * (A_BYTES + B_BYTES); };
+    auto sB = [&](int b) { return smem + b * (A_BYTES + B_BYTES) + A_BYTES; };
+    float* sInv = reinterpret_cast<float*>(smem + 2 * (A_BYTES + B_BYTES));   // [2][TM]
+    float* sBestV = sInv + 2 * TM;                                            // [4][TN]
+    int* sBestI = reinterpret_cast<int*>(sBestV + 4 * TN);                    // [4][TN]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1;   // pivot quarter (rows wr*64 .. +63 of the tile)
+    const int wc = wave & 1;    // target half   (cols wc*128 .. +127)
+    const int hi = lane >> 5;
+    const int l31 = lane & 31;
+
+    const int p = blockIdx.y;
+    const int chunk = blockIdx.x / ch.ppc;
+    if (p == 1 && chunk == 0 && ch.first_single) return;
+    const int kf = (p == 0 ? kf0 : kf1) + chunk;
+    const E* pv = piv + (int64_t)kf * S * D;
+    const float* inv = inv_norm + (int64_t)kf * S;
+    const int64_t t0 = chunk * ch.nS + (int64_t)(blockIdx.x - chunk * ch.ppc) * TN;
+    const int64_t t_end = (chunk + 1) * ch.nS;
+
+    const int n_mt_all = (S + TM - 1) / TM;
+    const int mt0 = blockIdx.z * tiles_per_split;
+    const int n_mt = min(tiles_per_split, n_mt_all - mt0);
+    const int n_kc = D / BK;
+    const int total = n_mt * n_kc;
+
+    // DMA pieces of this lane: wave w fills rows (w*4 + j)*8 .. +7 of both images, j = 0..3; lane -> row l/8, slot l%8
+    const int sub = lane >> 3, slot = lane & 7;
+    const E* b_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 8 + sub;
+        const int64_t row = min(t0 + r, t_end - 1);            // clamped duplicates: never written back
+        b_src[j] = tgt + row * D + ((slot ^ ((r >> 1) & 7)) << 3);
+    }
+    int a_off[4];   // element offset of this lane's piece inside the pivot tile (re-clamped per tile)
+    auto set_tile = [&](int mt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (wave * 4 + j) * 8 + sub;
+            const int row = min((mt0 + mt) * TM + r, S - 1);   // clamped duplicates can never win (see epilogue)
+            a_off[j] = row * D + ((slot ^ ((r >> 1) & 7)) << 3);
+        }
+    };
+    auto stage = [&](int it) {
+        const int mt = it / n_kc, kc = it - mt * n_kc;
+        const int b = it & 1;
+        if (kc == 0) {
+            set_tile(mt);
+            if (wave == 0) {   // the tile's inverse norms: 256 floats = one 1 KB DMA piece
+                const int row = min((mt0 + mt) * TM + lane * 4, S - 4);
+                __builtin_amdgcn_global_load_lds((glb_ptr)(inv + row), (lds_ptr)(sInv + (mt & 1) * TM), 16, 0, 0);
+            }
+        }
+        const int col = kc * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((glb_ptr)(pv + a_off[j] + col), (lds_ptr)(sA(b) + (wave * 4 + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(b_src[j] + col), (lds_ptr)(sB(b) + (wave * 4 + j) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[NI][WN];
+    float best_v[WN];
+    int best_i[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        best_v[j] = -INFINITY;
+        best_i[j] = 0;
+    }
+
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int it = 0; it < total; ++it) {
+        const int mt = it / n_kc, kc = it - mt * n_kc;
+        // buffer (it + 1) & 1 was last read in interval it - 1; every wave has passed the barrier that ended it
+        if (it + 1 < total) stage(it + 1);
+        if (kc == 0) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+        const unsigned char* a = sA(it & 1);
+        const unsigned char* b = sB(it & 1);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            vec8 fa[NI], fb[WN];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                fa[i] = __builtin_bit_cast(vec8, ld16(a + swz_off<BK>(wr * 64 + i * 32 + l31, ks * 2 + hi)));
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                fb[j] = __builtin_bit_cast(vec8, ld16(b + swz_off<BK>((wc * WN + j) * 32 + l31, ks * 2 + hi)));
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = T::mfma32(fa[i], fb[j], acc[i][j]);
+        }
+        if (kc == n_kc - 1) {
+            // argmax epilogue: rows visited in ascending order, strict '>' keeps the first maximum
+            const float* si = sInv + (mt & 1) * TM;
+            const int last = S - 1 - (mt0 + mt) * TM;   // rows past S are copies of row S - 1: give them ITS inverse norm
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = wr * 64 + i * 32 + cd_row(r, hi);
+                    const float w = si[min(rl, last)];
+                    const int gi = (mt0 + mt) * TM + rl;
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) {
+                        const float sc = acc[i][j][r] * w;
+                        if (sc > best_v[j]) {
+                            best_v[j] = sc;
+                            best_i[j] = gi;
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // merge lane l with lane l+32 (interleaved row sets): tie -> smaller index
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const float ov = __shfl_xor(best_v[j], 32);
+        const int oi = __shfl_xor(best_i[j], 32);
+        if (ov > best_v[j] || (ov == best_v[j] && oi < best_i[j])) {
+            best_v[j] = ov;
+            best_i[j] = oi;
+        }
+        if (hi == 0) {
+            const int col = (wc * WN + j) * 32 + l31;
+            sBestV[wr * TN + col] = best_v[j];
+            sBestI[wr * TN + col] = best_i[j];
+        }
+    }
+    __syncthreads();
+    if (tid < TN) {
+        float v0 = sBestV[tid];
+        int i0 = sBestI[tid];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {   // ascending pivot quarters: strict '>' keeps the first maximum
+            const float v1 = sBestV[q * TN + tid];
+            const int i1 = sBestI[q * TN + tid];
+            if (v1 > v0 || (v1 == v0 && i1 < i0)) {
+                i0 = i1;
+                v0 = v1;
+            }
+        }
+        i0 = i0 < S ? i0 : S - 1;
+        const int64_t t = t0 + tid;
+        if (t < t_end) {
+            if (part_out)
+                part_out[((int64_t)blockIdx.z * gridDim.y + p) * n_tgt + t] = NnPartial{v0, i0};
+            else
+                idx_out[(int64_t)p * n_tgt + t] = i0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Register-B variant for D = 16*DK: one wave = 32 targets whose B fragments stay in registers.
 template <typename T, int DK>
 __global__ __launch_bounds__(256, 3) void nn_search_rb_kernel(const typename T::elem* __restrict__ tgt,
@@ -412,7 +612,8 @@ enum NnKernel {
     NN_WIDE,    // generic kernel, 128-target panels, 64-wide D chunks
     NN_BK64,    // generic kernel, 64-target panels, 64-wide D chunks
     NN_BK128,   // few workgroups and a long contraction: 128-wide D chunks
-    NN_DEEP     // fewer still, D >= 1024: 64-pivot tiles and 256-wide D chunks (a quarter of the barrier intervals)
+    NN_DEEP,    // fewer still, D >= 1024: 64-pivot tiles and 256-wide D chunks (a quarter of the barrier intervals)
+    NN_GLDS     // D % 64 == 0, D >= 512, chip-filling grids: 256 x 256 workgroup tiles staged by LDS-DMA
 };
 struct NnPlan {
     int kern;
@@ -455,6 +656,25 @@ static NnPlan nn_plan(int64_t n_tgt, int S, int D, int P, int C = 1) {
         shape(128, 32);
         return pl;
     }
+#ifndef TF_TUNE_NN_NO_GLDS   // A/B switch of tools/build_variants.sh
+    // LDS-DMA kernel (256-target panels, 256-pivot tiles, one 8-wave workgroup per CU): where the launch still has
+    // >= TF_NN_GLDS_MIN_WGS workgroups after splitting the pivot range down to one tile per workgroup
+    if (D % 64 == 0 && D >= 512 && S % 4 == 0) {
+        static const int min_wgs = [] { const char* e = getenv("TF_NN_GLDS_MIN_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+        const int64_t panels = (n_tgt + 255) / 256;
+        const int n_tiles = (S + 255) / 256;
+        if (panels * C * P * n_tiles >= min_wgs) {
+            pl.kern = NN_GLDS;
+            pl.panels = panels;
+            // one workgroup per CU: aim at >= 3 rounds of workgroups (tail), never below one tile per split
+            int splits = 1;
+            while (panels * C * P * splits < 3 * 256 && splits * 2 <= n_tiles) splits *= 2;
+            pl.tiles_per_split = (n_tiles + splits - 1) / splits;
+            pl.splits = (n_tiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
+            return pl;
+        }
+    }
+#endif
     // 128-target panels halve the pivot re-reads; they pay as soon as the grid still fills the GPU after
     // splitting the pivot range (measured at cfg2 level 1, 5120 targets x 2 keyframes: 34.6 vs 39.8 us)
     if (((n_tgt + 127) / 128) * P * C >= 64) {
@@ -502,6 +722,24 @@ int launch_nn(const void* tgt, const void* piv, const float* inv_norm, int32_t* 
     return (fin && splits > 1) ? finalize(ws, idx, n_tgt * C * P, splits, st) : 0;
 }
 
+template <typename T>
+int launch_nn_glds(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, NnPartial* ws, int64_t n_tgt,
+                   int S, int D, int P, int kf0, int kf1, hipStream_t st, bool fin, int C, int first_single) {
+    constexpr size_t lds = 2 * (256 + 256) * 64 * 2 + 2 * 256 * 4 + 4 * 256 * 8;
+    static_assert(lds <= 160 * 1024, "LDS");
+    const NnPlan pl = nn_plan(n_tgt, S, D, P, C);
+    const int splits = pl.splits, tps = pl.tiles_per_split;
+    dim3 grid((unsigned)(pl.panels * C), (unsigned)P, (unsigned)splits);
+    auto kern = nn_search_glds_kernel<T>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const NnChunks ch{n_tgt, (int)pl.panels, first_single};
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, reinterpret_cast<const typename T::elem*>(tgt),
+                       reinterpret_cast<const typename T::elem*>(piv), inv_norm, idx,
+                       (splits > 1 || !fin) ? ws : nullptr, n_tgt * C, S, D, kf0, kf1, tps, ch);
+    TF_LAUNCH_CHECK("tf_nn_search");
+    return (fin && splits > 1) ? finalize(ws, idx, n_tgt * C * P, splits, st) : 0;
+}
+
 template <typename T, int DK>
 int launch_nn_rb(const void* tgt, const void* piv, const float* inv_norm, int32_t* idx, NnPartial* ws, int64_t n_tgt,
                  int S, int P, int kf0, int kf1, hipStream_t st, bool fin, int C, int first_single) {
@@ -524,6 +762,8 @@ int dispatch_nn(const void* tgt, const void* piv, const float* inv_norm, int32_t
     switch (nn_plan(n_tgt, S, D, P, C).kern) {
         case NN_RB:
             return launch_nn_rb<T, 20>(tgt, piv, inv_norm, idx, ws, n_tgt, S, P, kf0, kf1, st, fin, C, first_single);
+        case NN_GLDS:
+            return launch_nn_glds<T>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin, C, first_single);
         case NN_WIDE:
             return launch_nn<T, 2, 64, 128>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin, C, first_single);
         case NN_DEEP:

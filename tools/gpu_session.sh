@@ -31,6 +31,10 @@ for stage in "$@"; do
     hooksab)    for e in "TOKENFLOW_NORM1_ALL_BRANCHES=1" "TOKENFLOW_NORM1_ALL_BRANCHES=0" "TOKENFLOW_NORM1_ALL_BRANCHES=1" "TOKENFLOW_NORM1_ALL_BRANCHES=0"; do for a in "6 --graph" "10 --ranks 8 --wire-less --graph"; do echo -n "$e: " >> $O/hooks_norm1_ab.txt; env $e timeout 600 python tools/hooks_bench.py cfg2 $a >> $O/hooks_norm1_ab.txt 2>/dev/null; done; done; cat $O/hooks_norm1_ab.txt ;;
     onepassab)  for lib in "" il40nw4 "" il40nw4; do echo "== lib=${lib:-current}" | tee -a $O/rank_step_onepass_ab.txt
                   TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/rank_step_microbench.py --native --only onepass,auto --no-copies --reps 12 2>/dev/null | grep "step inject\|level 0" | tee -a $O/rank_step_onepass_ab.txt; done ;;
+    gldstests)  timeout 900 python -m pytest tests/test_fullsize_gpu.py tests/test_kernels_gpu.py tests/test_baseline_configs_gpu.py -q --tb=short -p no:cacheprovider -s -k "lds_dma or nn_search or propagat" 2>&1 | grep -v "^$" | tail -30 ;;
+    gldsab)     for e in "TF_NN_GLDS_MIN_WGS=100000000" "TF_NN_GLDS_MIN_WGS=256" "TF_NN_GLDS_MIN_WGS=100000000" "TF_NN_GLDS_MIN_WGS=256" "TF_NN_GLDS_MIN_WGS=64"; do echo "== $e" | tee -a $O/nn_glds_ab.txt
+                  env $e timeout 300 python tools/prop_microbench.py 8,5,1024,640 8,5,256,1280 10,8,2304,640 10,8,576,1280 25,8,1024,640 2>/dev/null | tee -a $O/nn_glds_ab.txt
+                  env $e timeout 300 python tools/nn_microbench.py 8,5,1024,640 8,5,256,1280 2>/dev/null | tee -a $O/nn_glds_ab.txt; done ;;
     trprobe)    timeout 60 tools/ubench/tr_probe > $O/tr_probe.txt 2>&1; cat $O/tr_probe.txt ;;
     fusedtests) timeout 900 python -m pytest tests/test_fused_attn_gpu.py -q --tb=line -p no:cacheprovider 2>&1 | tail -40 > $O/fused_tests.txt; tail -25 $O/fused_tests.txt ;;
     kerneltests) timeout 1500 python -m pytest tests/test_kernels_gpu.py -q --tb=line -p no:cacheprovider -k "attn" 2>&1 | tail -30 > $O/kernel_attn_tests.txt; tail -15 $O/kernel_attn_tests.txt ;;
