@@ -651,16 +651,15 @@ static NnPlan nn_plan(int64_t n_tgt, int S, int D, int P, int C = 1) {
         pl.splits = (n_tiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
         return pl.panels * C * P * pl.splits;   // workgroups of the launch
     };
-    if (D == 320) {
-        pl.kern = NN_RB;
-        shape(128, 32);
-        return pl;
-    }
 #ifndef TF_TUNE_NN_NO_GLDS   // A/B switch of tools/build_variants.sh
     // LDS-DMA kernel (256-target panels, 256-pivot tiles, one 8-wave workgroup per CU): where the launch still has
     // >= TF_NN_GLDS_MIN_WGS workgroups after splitting the pivot range down to one tile per workgroup
-    if (D % 64 == 0 && D >= 512 && S % 4 == 0) {
-        static const int min_wgs = [] { const char* e = getenv("TF_NN_GLDS_MIN_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+    static const int glds_min_d = [] { const char* e = getenv("TF_NN_GLDS_MIN_D"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    // D = 320 keeps the register-B kernel at the large levels (1.00 vs 1.12 ms at cfg2 level 0); with <= 1024 pivots per
+    // keyframe (BASELINE config 1, level 0) its 32-pivot tiles are mostly prologue: 44 -> 33 us (profiles/r05_nn_glds_ab.txt)
+    if (D % 64 == 0 && (D >= glds_min_d || (D == 320 && S <= 1024)) && S % 4 == 0) {
+        static const int min_wgs = [] { const char* e = getenv("TF_NN_GLDS_MIN_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 160; }();
+        static const int rounds = [] { const char* e = getenv("TF_NN_GLDS_ROUNDS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 3; }();
         const int64_t panels = (n_tgt + 255) / 256;
         const int n_tiles = (S + 255) / 256;
         if (panels * C * P * n_tiles >= min_wgs) {
@@ -668,13 +667,18 @@ static NnPlan nn_plan(int64_t n_tgt, int S, int D, int P, int C = 1) {
             pl.panels = panels;
             // one workgroup per CU: aim at >= 3 rounds of workgroups (tail), never below one tile per split
             int splits = 1;
-            while (panels * C * P * splits < 3 * 256 && splits * 2 <= n_tiles) splits *= 2;
+            while (panels * C * P * splits < rounds * 256 && splits * 2 <= n_tiles) splits *= 2;
             pl.tiles_per_split = (n_tiles + splits - 1) / splits;
             pl.splits = (n_tiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
             return pl;
         }
     }
 #endif
+    if (D == 320) {
+        pl.kern = NN_RB;
+        shape(128, 32);
+        return pl;
+    }
     // 128-target panels halve the pivot re-reads; they pay as soon as the grid still fills the GPU after
     // splitting the pivot range (measured at cfg2 level 1, 5120 targets x 2 keyframes: 34.6 vs 39.8 us)
     if (((n_tgt + 127) / 128) * P * C >= 64) {

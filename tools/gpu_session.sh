@@ -35,6 +35,13 @@ for stage in "$@"; do
     gldsab)     for e in "TF_NN_GLDS_MIN_WGS=100000000" "TF_NN_GLDS_MIN_WGS=256" "TF_NN_GLDS_MIN_WGS=100000000" "TF_NN_GLDS_MIN_WGS=256" "TF_NN_GLDS_MIN_WGS=64"; do echo "== $e" | tee -a $O/nn_glds_ab.txt
                   env $e timeout 300 python tools/prop_microbench.py 8,5,1024,640 8,5,256,1280 10,8,2304,640 10,8,576,1280 25,8,1024,640 2>/dev/null | tee -a $O/nn_glds_ab.txt
                   env $e timeout 300 python tools/nn_microbench.py 8,5,1024,640 8,5,256,1280 2>/dev/null | tee -a $O/nn_glds_ab.txt; done ;;
+    gldsrounds) for e in "TF_NN_GLDS_ROUNDS=3" "TF_NN_GLDS_ROUNDS=5" "TF_NN_GLDS_ROUNDS=9" "TF_NN_GLDS_ROUNDS=3" "TF_NN_GLDS_ROUNDS=5"; do echo "== $e" | tee -a $O/nn_glds_rounds.txt
+                  env $e timeout 300 python tools/prop_microbench.py 8,5,1024,640 10,8,2304,640 10,8,576,1280 25,8,1024,640 25,8,256,1280 2>/dev/null | grep "one call" | tee -a $O/nn_glds_rounds.txt
+                  env $e timeout 300 python tools/nn_microbench.py 8,5,1024,640 2>/dev/null | tee -a $O/nn_glds_rounds.txt; done ;;
+    glds320)    for e in "TF_NN_GLDS_MIN_D=512" "TF_NN_GLDS_MIN_D=320" "TF_NN_GLDS_MIN_D=512" "TF_NN_GLDS_MIN_D=320"; do echo "== $e" | tee -a $O/nn_glds_d320.txt
+                  env $e timeout 300 python tools/prop_microbench.py 8,5,4096,320 10,8,9216,320 4,2,1024,320 2>/dev/null | tee -a $O/nn_glds_d320.txt
+                  env $e timeout 300 python tools/nn_microbench.py 8,5,4096,320 2>/dev/null | tee -a $O/nn_glds_d320.txt; done
+                TF_NN_GLDS_MIN_D=320 timeout 600 python -m pytest tests/test_fullsize_gpu.py tests/test_kernels_gpu.py -q --tb=short -p no:cacheprovider -k "nn_search or propagat" 2>&1 | tail -3 | tee -a $O/nn_glds_d320.txt ;;
     trprobe)    timeout 60 tools/ubench/tr_probe > $O/tr_probe.txt 2>&1; cat $O/tr_probe.txt ;;
     fusedtests) timeout 900 python -m pytest tests/test_fused_attn_gpu.py -q --tb=line -p no:cacheprovider 2>&1 | tail -40 > $O/fused_tests.txt; tail -25 $O/fused_tests.txt ;;
     kerneltests) timeout 1500 python -m pytest tests/test_kernels_gpu.py -q --tb=line -p no:cacheprovider -k "attn" 2>&1 | tail -30 > $O/kernel_attn_tests.txt; tail -15 $O/kernel_attn_tests.txt ;;
