@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TF_ABI_VERSION 5
+#define TF_ABI_VERSION 6
 
 /* Every entry point below is exported with default visibility; the library itself is built with -fvisibility=hidden, so
  * its exported symbols are exactly the declarations of this header (checked by tests/test_hooks_cpu.py). */
@@ -333,6 +333,8 @@ TF_API int tf_inject_copy(void* x, int64_t elems_per_branch, int elem_bytes, voi
  * handed to the others by the host (file, socket, MPI ...).
  * ------------------------------------------------------------------------ */
 typedef struct tf_comm tf_comm;
+TF_API int tf_comm_available(void);   /* 0 if RCCL can be loaded and has every entry point used here; starts no
+                                         bootstrap listener (a pre-flight probe: tf_comm_unique_id does start one) */
 TF_API int tf_comm_unique_id(void* id_out_128_bytes);
 TF_API int tf_comm_init(const void* unique_id_128_bytes, int rank, int world, tf_comm** comm_out);
 

@@ -21,7 +21,7 @@ def attn_hint(qw: int = 0, kw: int = 0, qb: int = 1) -> int:
     return (code[qw] << 8) | (code[kw] << 11) | (TF_ATTN_HINT_QB2 if qb == 2 else 0)
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 TF_RANK_HEADS, TF_RANK_BANK, TF_RANK_SLOTS, TF_RANK_NO_HALO, TF_RANK_INV_NORM = 0, 1, 64, 16, 32
 TF_ERR_COMM = -6
 
@@ -58,6 +58,7 @@ _SIGNATURES = {
     "tf_ddim_step": (_c.c_int, [_c.c_void_p] * 3 + [_c.c_int64] + [_c.c_float] * 4 + [_c.c_int, _c.c_void_p]),
     "tf_inject_copy": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p]),
     # multi-GPU exchange steps over RCCL (tokenflow_amd/comm.py; the sharded host path uses torch.distributed instead)
+    "tf_comm_available": (_c.c_int, []),
     "tf_comm_unique_id": (_c.c_int, [_c.c_void_p]),
     "tf_comm_init": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p]),
     "tf_comm_destroy": (_c.c_int, [_c.c_void_p]),

@@ -183,7 +183,9 @@ def bootstrap(rank: int, world: int, n: int = 1, group=None, make=None):
     pre = None
     if make is HipComm:
         try:
-            HipComm.unique_id()             # dlopen of librccl + every symbol, on THIS rank
+            # dlopen of librccl + every symbol, on THIS rank; a loader-only call: ncclGetUniqueId would start a
+            # bootstrap root listener (thread + socket) on every rank for nothing
+            _lib.check(_lib.load().tf_comm_available(), "tf_comm_available")
             torch.cuda.current_device()
         except Exception as e:  # noqa: BLE001
             pre = str(e)

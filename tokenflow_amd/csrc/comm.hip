@@ -139,6 +139,11 @@ int loop_all_to_all(const tf_comm* c, const void* send, void* recv, const int64_
         }                                                                         \
     } while (0)
 
+extern "C" int tf_comm_available(void) {
+    TF_NEED_RCCL("tf_comm_available");   // dlopen of librccl + every symbol this file calls; starts nothing
+    return 0;
+}
+
 extern "C" int tf_comm_unique_id(void* id_out) {
     TF_ARG(id_out, TF_ERR_NULL, "tf_comm_unique_id: null pointer");
     TF_NEED_RCCL("tf_comm_unique_id");

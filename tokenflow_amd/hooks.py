@@ -441,6 +441,11 @@ def _shard_state(block, shard, S: int, D: int, dtype, device):
     key = (shard.Kl, S, D, dtype, device)
     st = block.__dict__.get("_tf_shard_state")
     if st is None or st[0] != key:
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            # the state outlives any one graph (the pivotal pass writes it, every chunk pass of the step reads it, eager
+            # passes reuse it): it must not come from a capture's private pool
+            raise RuntimeError("register_frame_shard: the per-block propagation state would be allocated inside a HIP-graph "
+                               "capture; run one eager pivotal pass first (GraphCache(warmup >= 1) does)")
         Kl = shard.Kl
         st = (key, torch.empty(1 + 3 * Kl, S, D, dtype=dtype, device=device),
               torch.empty(1 + 3 * Kl, S, dtype=torch.float32, device=device),
@@ -512,6 +517,13 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
                 dest = None
                 shard0 = _active_shard(self) if self.pivotal_pass else None
                 if shard0 is not None and n_frames == shard0.Kl and hidden_states.is_cuda:
+                    # a neighbour halo of the PREVIOUS pivotal pass may still be in flight if no chunk pass (and no
+                    # join_frame_shard) consumed it: its send reads, and its receive writes, the state this pass is
+                    # about to overwrite -- order behind it first
+                    prev = self.__dict__.get("_tf_halo")
+                    if prev is not None and prev[3]:
+                        shard0.halo_wait(prev[3])
+                        self.__dict__["_tf_halo"] = (prev[0], prev[1], prev[2], [])
                     # sharded pivotal pass: norm1 writes straight into the block's halo-extended state
                     def dest(dt, _s=shard0):
                         nb, ib, _ = _shard_state(self, _s, sequence_length, dim, dt, hidden_states.device)
