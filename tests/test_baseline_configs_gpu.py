@@ -244,7 +244,10 @@ def test_ext_attn_cfg4_cfg5_sampled_rows(name, dtype):
     39 GiB per head and branch) on sampled query rows of sampled (branch, frame, head) problems against the
     fp32 oracle.  Tolerance: per-token deviation < 1e-3 (north star) as the plain number on the fp32 output
     (TF_ATTN_OUT_F32); the 16-bit output within 1e-3 + half an ulp of the reference value (what any tensor of that
-    type is off by), and for f16 also within its parity bound 2e-4 + 2^-11 (|ref| + softmax.|V|)."""
+    type is off by), and for f16 also within its parity bound 2e-4 + 2^-11 (|ref| + softmax.|V|).
+    (Rounds 1-3 asserted the plain 1e-3 on the bf16 OUTPUT tensor, which held only because |out| < 0.25 at these bank
+    sizes; round 4 moved the absolute check to the fp32 output -- the quantity the kernel controls -- and bounds the
+    16-bit tensor by its own format: half an ulp of a bf16 value in [0.5, 1) is already 1.95e-3.)"""
     ops = _ops()
     K, S, h, d, variants = CFG45[name]
     D = h * d

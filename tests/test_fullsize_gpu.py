@@ -77,7 +77,9 @@ def test_ext_attn_injection_equals_aliased_inputs(S):
     S = 1024: the call without injection takes the half-tile interleaved kernel, whose softmax reference point moves
     per 32 keys instead of 64 -- P is then rounded against a different shift, so the two are independent roundings of
     the same result: EACH is within 2e-4 + 2^-8 |ref| of it (the attention bound of tests/test_kernels_gpu.py; its
-    P-rounding term averages out over 8192 keys), hence they differ by at most twice that."""
+    P-rounding term averages out over 8192 keys), hence they differ by at most twice that: 2 x 2e-4 = the 4e-4 asserted
+    (up to round 3 both calls ran ONE kernel family at S = 1024 too and the absolute term was a single 2e-4; round 4's
+    lagged reference point made the interleaved kernel's shift differ from the dual kernel's)."""
     ops = _ops()
     K, h, d = 8, 8, 80
     g = torch.Generator(device="cuda").manual_seed(7)
