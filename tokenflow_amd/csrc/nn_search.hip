@@ -593,6 +593,132 @@ __global__ __launch_bounds__(256, 3) void nn_search_rb_kernel(const typename T::
     }
 }
 
+// ---------------------------------------------------------------------------
+// Register-B variant with the pivot tiles staged by LDS-DMA (global_load_lds_dwordx4) instead of through registers:
+// no staging VGPRs, no ds_write pass.  The DMA writes lane-linearly, so the image has no row padding; bank conflicts of
+// the fragment reads (32 rows, 640-B stride) are avoided by an XOR swizzle of the 16-B piece index with (row >> 1) & 7,
+// applied on the SOURCE address of the DMA and on the read (the same involution; it permutes inside aligned groups of
+// 8 pieces, D / 8 being a multiple of 8).  Same arithmetic as nn_search_rbg_kernel.
+template <typename T, int DK>
+__global__ __launch_bounds__(256, 3) void nn_search_rbg_kernel(const typename T::elem* __restrict__ tgt,
+                                                           const typename T::elem* __restrict__ piv,
+                                                           const float* __restrict__ inv_norm,
+                                                           int32_t* __restrict__ idx_out,
+                                                           NnPartial* __restrict__ part_out, int64_t n_tgt, int S,
+                                                           int kf0, int kf1, int tiles_per_split, NnChunks ch) {
+    typedef typename T::elem E;
+    typedef typename T::vec8 vec8;
+    constexpr int D = 16 * DK;
+    constexpr int TMR = 32;                  // pivots per tile
+    constexpr int RS = D;                    // LDS row stride (elements): the DMA image is dense
+    static_assert((D / 8) % 8 == 0, "the swizzle permutes inside groups of 8 pieces");
+    constexpr int NPIECE = TMR * D * 2 / 1024;   // 1 KB DMA pieces per tile (20 at D = 320)
+    static_assert(NPIECE % 4 == 0, "pieces split evenly over the 4 waves");
+    constexpr int A_ELEMS = TMR * RS;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    auto sA = [&](int b) { return reinterpret_cast<E*>(smem) + b * A_ELEMS; };
+    float* sInv = reinterpret_cast<float*>(smem + 2 * A_ELEMS * sizeof(E));  // [2][TMR]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int hi = lane >> 5;
+    const int l31 = lane & 31;
+    const int p = blockIdx.y;
+    const int chunk = blockIdx.x / ch.ppc;       // see nn_search_kernel
+    if (p == 1 && chunk == 0 && ch.first_single) return;
+    const int kf = (p == 0 ? kf0 : kf1) + chunk;
+    const E* pv = piv + (int64_t)kf * S * D;
+    const float* inv = inv_norm + (int64_t)kf * S;
+    const int64_t t_end = (chunk + 1) * ch.nS;
+    const int64_t t_row = chunk * ch.nS + (int64_t)(blockIdx.x - chunk * ch.ppc) * 128 + wave * 32 + l31;
+
+    const int n_mt_all = (S + TMR - 1) / TMR;
+    const int mt0 = blockIdx.z * tiles_per_split;
+    const int n_mt = min(tiles_per_split, n_mt_all - mt0);
+
+    vec8 fb[DK];
+    {
+        const E* tp = tgt + (t_row < t_end ? t_row : t_end - 1) * D + 8 * hi;
+#pragma unroll
+        for (int t = 0; t < DK; ++t) fb[t] = __builtin_bit_cast(vec8, ld16(tp + 16 * t));
+    }
+
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // this lane's slot of DMA piece j = wave + 4 * i: byte o of the image -> row o / (2 D), position (o % (2 D)) / 16
+    // (S % 32 == 0 in this variant: every tile is full, no row clamp)
+    int a_off[NPIECE / 4];
+#pragma unroll
+    for (int i = 0; i < NPIECE / 4; ++i) {
+        const int o = (wave_u + 4 * i) * 1024 + lane * 16;
+        const int r = o / (2 * D), pos = (o - r * 2 * D) >> 4;
+        a_off[i] = r * D + ((pos ^ ((r >> 1) & 7)) << 3);
+    }
+    float rinv = 0.f;
+    auto stage_load = [&](int mt) {
+        unsigned char* a = reinterpret_cast<unsigned char*>(sA(mt & 1));
+        const E* tile = pv + (int64_t)(mt0 + mt) * TMR * D;
+#pragma unroll
+        for (int i = 0; i < NPIECE / 4; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(tile + a_off[i]), (lds_ptr)(a + (wave_u + 4 * i) * 1024), 16, 0, 0);
+        if (tid < TMR) {
+            int row = (mt0 + mt) * TMR + tid;
+            rinv = inv[row < S ? row : S - 1];
+        }
+    };
+    auto stage_write = [&](int mt) {
+        if (tid < TMR) sInv[(mt & 1) * TMR + tid] = rinv;
+    };
+
+    float best_v = -INFINITY;
+    int best_i = 0;
+    stage_load(0);
+    stage_write(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int mt = 0; mt < n_mt; ++mt) {
+        const bool has_next = mt + 1 < n_mt;
+        if (has_next) stage_load(mt + 1);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const E* arow = sA(mt & 1) + l31 * RS;
+        const int swz = (l31 >> 1) & 7;
+#pragma unroll
+        for (int t = 0; t < DK; ++t)
+            acc = T::mfma32(__builtin_bit_cast(vec8, ld16(arow + (((2 * t + hi) ^ swz) << 3))), fb[t], acc);
+        const float* si = sInv + (mt & 1) * TMR;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = cd_row(r, hi);
+            const float sc = acc[r] * si[rl];
+            if (sc > best_v) {
+                best_v = sc;
+                best_i = (mt0 + mt) * TMR + rl;
+            }
+        }
+        if (has_next) stage_write(mt + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const float ov = __shfl_xor(best_v, 32);
+    const int oi = __shfl_xor(best_i, 32);
+    if (ov > best_v || (ov == best_v && oi < best_i)) {
+        best_v = ov;
+        best_i = oi;
+    }
+    best_i = best_i < S ? best_i : S - 1;
+    if (hi == 0 && t_row < t_end) {
+        if (part_out)
+            part_out[((int64_t)blockIdx.z * gridDim.y + p) * n_tgt + t_row] = NnPartial{best_v, best_i};
+        else
+            idx_out[(int64_t)p * n_tgt + t_row] = best_i;
+    }
+}
+
 // merge the per-split candidates: ascending split order == ascending pivot index
 __global__ __launch_bounds__(256) void nn_finalize_kernel(const NnPartial* __restrict__ part,
                                                           int32_t* __restrict__ idx_out, int64_t total, int splits) {
@@ -753,6 +879,17 @@ int launch_nn_rb(const void* tgt, const void* piv, const float* inv_norm, int32_
     const int splits = pl.splits, tps = pl.tiles_per_split;
     dim3 grid((unsigned)(pl.panels * C), (unsigned)P, (unsigned)splits);
     const NnChunks ch{n_tgt, (int)pl.panels, first_single};
+    // pivot tiles by LDS-DMA where every tile is full (S % 32 == 0): +1.4 % at cfg2 / cfg4 level 0
+    // (profiles/r05_nn_glds_ab.txt: 1028 -> 1014 us, 8826 -> 8746 us per block); TF_NN_RB_GLDS=0: the register-staged kernel
+    static const bool dma = [] { const char* e = getenv("TF_NN_RB_GLDS"); return !e || atoi(e) != 0; }();
+    if (dma && S % 32 == 0) {
+        const size_t lds_g = 2 * 32 * D * 2 + 2 * 32 * 4;
+        hipLaunchKernelGGL((nn_search_rbg_kernel<T, DK>), grid, dim3(256), lds_g, st,
+                           reinterpret_cast<const typename T::elem*>(tgt), reinterpret_cast<const typename T::elem*>(piv),
+                           inv_norm, idx, (splits > 1 || !fin) ? ws : nullptr, n_tgt * C, S, kf0, kf1, tps, ch);
+        TF_LAUNCH_CHECK("tf_nn_search");
+        return (fin && splits > 1) ? finalize(ws, idx, n_tgt * C * P, splits, st) : 0;
+    }
     hipLaunchKernelGGL((nn_search_rb_kernel<T, DK>), grid, dim3(256), lds, st,
                        reinterpret_cast<const typename T::elem*>(tgt), reinterpret_cast<const typename T::elem*>(piv),
                        inv_norm, idx, (splits > 1 || !fin) ? ws : nullptr, n_tgt * C, S, kf0, kf1, tps, ch);

@@ -44,6 +44,10 @@ for stage in "$@"; do
                 TF_NN_GLDS_MIN_D=320 timeout 600 python -m pytest tests/test_fullsize_gpu.py tests/test_kernels_gpu.py -q --tb=short -p no:cacheprovider -k "nn_search or propagat" 2>&1 | tail -3 | tee -a $O/nn_glds_d320.txt ;;
     hookstrace) rm -rf /tmp/ht; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/ht -- python $GRAFT_REPO_ROOT/tools/hooks_bench.py cfg2 6 > /dev/null 2>&1 )
                 python tools/rocpd_stats.py $(find /tmp/ht -name "*_results.db" | head -1) > $O/hooks_kernel_stats.csv; head -40 $O/hooks_kernel_stats.csv | cut -c1-200 ;;
+    rbgab)      for e in "TF_NN_RB_GLDS=0" "TF_NN_RB_GLDS=1" "TF_NN_RB_GLDS=0" "TF_NN_RB_GLDS=1"; do echo "== $e" | tee -a $O/nn_rb_glds_ab.txt
+                  env $e timeout 300 python tools/prop_microbench.py 8,5,4096,320 10,8,9216,320 2>/dev/null | grep "one call" | tee -a $O/nn_rb_glds_ab.txt
+                  env $e timeout 300 python tools/nn_microbench.py 8,5,4096,320 10,8,9216,320 2>/dev/null | tee -a $O/nn_rb_glds_ab.txt; done
+                TF_NN_RB_GLDS=1 timeout 600 python -m pytest tests/test_fullsize_gpu.py tests/test_kernels_gpu.py -q --tb=short -p no:cacheprovider -k "nn_search or propagat" 2>&1 | tail -3 | tee -a $O/nn_rb_glds_ab.txt ;;
     trprobe)    timeout 60 tools/ubench/tr_probe > $O/tr_probe.txt 2>&1; cat $O/tr_probe.txt ;;
     fusedtests) timeout 900 python -m pytest tests/test_fused_attn_gpu.py -q --tb=line -p no:cacheprovider 2>&1 | tail -40 > $O/fused_tests.txt; tail -25 $O/fused_tests.txt ;;
     kerneltests) timeout 1500 python -m pytest tests/test_kernels_gpu.py -q --tb=line -p no:cacheprovider -k "attn" 2>&1 | tail -30 > $O/kernel_attn_tests.txt; tail -15 $O/kernel_attn_tests.txt ;;
