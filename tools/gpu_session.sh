@@ -95,7 +95,7 @@ for stage in "$@"; do
                   rm -rf /tmp/p1; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/p1 -- python $GRAFT_REPO_ROOT/tools/attn_microbench.py 8,1024,8,80 > /dev/null 2>&1 )
                   python tools/rocpd_pmc.py $(find /tmp/p1 -name "*_results.db" | head -1) | grep "ext_attn_il_kernel\|^kernel" >> $O/pmc_l1.csv
                   rm -rf /tmp/p2; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/p2 -- python $GRAFT_REPO_ROOT/tools/prop_microbench.py 8,5,1024,640 > /dev/null 2>&1 )
-                  python tools/rocpd_pmc.py $(find /tmp/p2 -name "*_results.db" | head -1) | grep "nn_search_kernel" | grep "x2x8" >> $O/pmc_l1.csv; done
+                  python tools/rocpd_pmc.py $(find /tmp/p2 -name "*_results.db" | head -1) | grep "nn_search_glds_kernel" >> $O/pmc_l1.csv; done
                 cut -c1-60,100-220 $O/pmc_l1.csv ;;
     newtests)   timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "sharded_rank or loopback_transport or into_caller or nn_search_shapes" 2>&1 | tail -30 ;;
     hooktests)  timeout 1500 python -m pytest tests/test_baseline_configs_gpu.py tests/test_sharded_gpu.py -q --tb=short -p no:cacheprovider -x -k "hooks or hipgraph or cfg1" 2>&1 | tail -15 ;;
