@@ -349,10 +349,19 @@ __global__ __launch_bounds__(512, 2) void nn_search_glds_kernel(const typename T
             a_off[j] = row * D + ((slot ^ ((r >> 1) & 7)) << 3);
         }
     };
-    auto stage = [&](int it) {
+    // DMA pieces j = 0..3 of chunk `it` (one A and one B piece each), issued as one block in front of the k-loop of the
+    // chunk in flight.  Spreading them over the k-steps, each pair behind a k-step's 8 MFMAs and pinned there with
+    // sched_barriers (TF_TUNE_GLDS_SPREAD_ISSUE), measured 1-4 % slower (profiles/r05_nn_glds_ab.txt): with two waves per
+    // SIMD the other wave's MFMAs already cover a wave's issue time, and the pinning costs the compiler its own order.
+#ifdef TF_TUNE_GLDS_SPREAD_ISSUE
+    constexpr bool SPREAD = true;
+#else
+    constexpr bool SPREAD = false;
+#endif
+    auto stage_piece = [&](int it, int j) {
         const int mt = it / n_kc, kc = it - mt * n_kc;
         const int b = it & 1;
-        if (kc == 0) {
+        if (j == 0 && kc == 0) {
             set_tile(mt);
             if (wave == 0) {   // the tile's inverse norms: 256 floats = one 1 KB DMA piece
                 const int row = min((mt0 + mt) * TM + lane * 4, S - 4);
@@ -360,11 +369,12 @@ __global__ __launch_bounds__(512, 2) void nn_search_glds_kernel(const typename T
             }
         }
         const int col = kc * BK;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(pv + a_off[j] + col), (lds_ptr)(sA(b) + (wave * 4 + j) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)(b_src[j] + col), (lds_ptr)(sB(b) + (wave * 4 + j) * 1024), 16, 0, 0);
+    };
+    auto stage = [&](int it) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((glb_ptr)(pv + a_off[j] + col), (lds_ptr)(sA(b) + (wave * 4 + j) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr)(b_src[j] + col), (lds_ptr)(sB(b) + (wave * 4 + j) * 1024), 16, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j) stage_piece(it, j);
     };
 
     f32x16 acc[NI][WN];
@@ -383,7 +393,8 @@ __global__ __launch_bounds__(512, 2) void nn_search_glds_kernel(const typename T
     for (int it = 0; it < total; ++it) {
         const int mt = it / n_kc, kc = it - mt * n_kc;
         // buffer (it + 1) & 1 was last read in interval it - 1; every wave has passed the barrier that ended it
-        if (it + 1 < total) stage(it + 1);
+        const bool more = it + 1 < total;
+        if (!SPREAD && more) stage(it + 1);
         if (kc == 0) {
 #pragma unroll
             for (int i = 0; i < NI; ++i)
@@ -407,6 +418,11 @@ __global__ __launch_bounds__(512, 2) void nn_search_glds_kernel(const typename T
             for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j) acc[i][j] = T::mfma32(fa[i], fb[j], acc[i][j]);
+            if (SPREAD) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) stage_piece(it + 1, ks);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (kc == n_kc - 1) {
             // argmax epilogue: rows visited in ascending order, strict '>' keeps the first maximum

@@ -48,6 +48,10 @@ for stage in "$@"; do
                   env $e timeout 300 python tools/prop_microbench.py 8,5,4096,320 10,8,9216,320 2>/dev/null | grep "one call" | tee -a $O/nn_rb_glds_ab.txt
                   env $e timeout 300 python tools/nn_microbench.py 8,5,4096,320 10,8,9216,320 2>/dev/null | tee -a $O/nn_rb_glds_ab.txt; done
                 TF_NN_RB_GLDS=1 timeout 600 python -m pytest tests/test_fullsize_gpu.py tests/test_kernels_gpu.py -q --tb=short -p no:cacheprovider -k "nn_search or propagat" 2>&1 | tail -3 | tee -a $O/nn_rb_glds_ab.txt ;;
+    gldsspread) for lib in gldsblock "" gldsblock ""; do echo "== lib=${lib:-current (DMA pieces spread over the k-steps)}" | tee -a $O/nn_glds_spread_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/prop_microbench.py 8,5,1024,640 10,8,2304,640 25,8,1024,640 10,8,576,1280 4,2,1024,320 2>/dev/null | grep "one call" | tee -a $O/nn_glds_spread_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/nn_microbench.py 8,5,1024,640 2>/dev/null | tee -a $O/nn_glds_spread_ab.txt; done
+                timeout 600 python -m pytest tests/test_fullsize_gpu.py tests/test_kernels_gpu.py -q --tb=short -p no:cacheprovider -k "lds_dma or nn_search or propagat" 2>&1 | tail -3 | tee -a $O/nn_glds_spread_ab.txt ;;
     trprobe)    timeout 60 tools/ubench/tr_probe > $O/tr_probe.txt 2>&1; cat $O/tr_probe.txt ;;
     fusedtests) timeout 900 python -m pytest tests/test_fused_attn_gpu.py -q --tb=line -p no:cacheprovider 2>&1 | tail -40 > $O/fused_tests.txt; tail -25 $O/fused_tests.txt ;;
     kerneltests) timeout 1500 python -m pytest tests/test_kernels_gpu.py -q --tb=line -p no:cacheprovider -k "attn" 2>&1 | tail -30 > $O/kernel_attn_tests.txt; tail -15 $O/kernel_attn_tests.txt ;;
