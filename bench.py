@@ -33,8 +33,12 @@ Prints ONE JSON line (rank 0):
                 injected calls (dual-V kernel + source launch), with the flops it actually executes next to the
                 algorithmic figure.  `traffic` is the HBM byte count of one plain launch from rocprofv3 PMC passes
                 (profiles/traffic.json; collected separately, never in this run) or null.
-  parity        in-run check against the oracle (after the timed region, rank 0, N = 1): max |out - ref| of the
-                level-0 attention on sampled rows, and the tie-aware NN index mismatch rate of a level-0 chunk.
+  parity        in-run check against the oracle (after the timed region, rank 0, N = 1), one block per level, bf16 and
+                f16: `attn_linf_fp32_out` (the normalised fp32 accumulator) against the tolerance 1e-3, the boolean
+                `attn_16bit_within_half_ulp` for the 16-bit output tensor, and the tie-aware NN index mismatch / raw
+                index-diff rates of a chunk for BOTH target flavours of SURVEY 8(d): video-like and iid (`*_iid`).
+  input_sets    step i runs on input set i % n; set s, block b is seeded 1234 + 16 s + b; all sets are
+                generated before the timed region (up to 8, at most 64 GB).
   roofline_other  NN search (MFMA roof) and gather/blend (HBM roof) on one level-0 chunk, HIP events, after the timed
                 region (rank 0, N = 1).
   yardstick     same box, same run, after the timed region (rank 0, N = 1): what the vendor libraries reach -- hipBLASLt

@@ -5,9 +5,10 @@
 #   tools/scale.sh [out-dir]            N = 1, 2, 4, 8; backends nccl (torch.distributed) and native (tf_rank_pivotal)
 #   GPUS="1 2 8" BACKENDS="nccl" STEPS=20 WARMUP=5 tools/scale.sh out
 #
-# Per (N, backend) one bench.py line (JSON) in <out-dir>/scale_<backend>_<N>.json: `ms_per_step` = the form whose results
-# equal the single-GPU run bit for bit, `ms_per_step_split` = the split form of the rank's attention; then the two-GPU
-# RCCL tests (skipped on a 1-GPU box) and a table of value / ms_per_step / ms_per_step_split / speed-up over N = 1.
+# Per (N, backend) one bench.py line (JSON) in <out-dir>/scale_<backend>_<N>.json: `ms_per_step` / `value` = the faster of
+# the two verified forms of the rank's attention (`value_form` names it), `ms_per_step_bit_identical` = the one-pass form
+# (equal to the bit-stable single-GPU run bit for bit), `ms_per_step_split` = the split form; then the two-GPU RCCL tests
+# (skipped on a 1-GPU box) and a table of value / the two timings / speed-up over N = 1.
 set -u
 cd "$(dirname "$0")/.." || exit 1
 export HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -41,7 +42,7 @@ for path in sorted(glob.glob(os.path.join(sys.argv[1], "scale_*.json"))):
     except Exception:
         continue
     b = os.path.basename(path).split("_")[1]
-    rows.append((b, d["n_gpus"], d["value"], d["ms_per_step"], d.get("ms_per_step_split")))
+    rows.append((b, d["n_gpus"], d["value"], d.get("ms_per_step_bit_identical") or d["ms_per_step"], d.get("ms_per_step_split")))
 base = next((r[3] for r in rows if r[1] == 1), None)
 print("backend  N  frames/s  ms/step (bit-identical)  ms/step (split)  speed-up (bit-identical / split)")
 for b, n, v, ms, mss in sorted(rows, key=lambda r: (r[0], r[1])):
