@@ -357,7 +357,10 @@ def test_ext_attn_strongly_negative_first_tile(d, dtype):
 
 # ------------------------------------------------------------------------------------------- multi-chunk propagation
 @pytest.mark.parametrize("K,n,S,D", [(8, 5, 4096, 320), (8, 5, 1024, 640), (4, 2, 64, 1280), (4, 2, 16, 1280),
-                                     (5, 3, 200, 72), (3, 8, 576, 1280), (3, 3, 200, 320), (4, 1, 45, 320)])
+                                     (5, 3, 200, 72), (3, 8, 576, 1280), (3, 3, 200, 320), (4, 1, 45, 320),
+                                     # multi-chunk launches of the LDS-DMA search whose pivot tile is the whole frame
+                                     # (cfg5 level 2) / half empty (128 pivots in a 256-row tile), and cfg1 level 0
+                                     (12, 8, 256, 1280), (24, 8, 128, 1280), (4, 2, 1024, 320)])
 @pytest.mark.parametrize("first", [0, 1])
 @pytest.mark.parametrize("res_dtype", [torch.bfloat16, torch.float32])
 def test_propagate_chunks_equals_per_chunk_calls(K, n, S, D, first, res_dtype):
