@@ -322,6 +322,23 @@ def test_library_exports_every_declared_symbol():
     assert {n for n in exported if "tf_" in n} == declared, {n for n in exported if "tf_" in n} ^ declared
 
 
+def test_comm_available_is_a_loader_only_probe():
+    """tf_comm_available: 0 where RCCL and every entry point the library binds can be loaded, else TF_ERR_COMM with the
+    reason in tf_last_error -- and no thread / socket either way (`bootstrap`'s pre-flight calls it on every rank;
+    ncclGetUniqueId, which it replaced there, starts a bootstrap listener per call)."""
+    import os
+    from tokenflow_amd import _lib
+    lib = _lib.load()
+    tasks = lambda: len(os.listdir("/proc/self/task"))       # native threads of this process
+    before = tasks()
+    rc = lib.tf_comm_available()
+    assert rc in (0, _lib.TF_ERR_COMM)
+    if rc:
+        assert lib.tf_last_error()
+    assert lib.tf_comm_available() == rc          # resolved once per process: the answer is stable
+    assert tasks() == before
+
+
 @pytest.mark.parametrize("dtype,sfx", [(torch.float32, ""), (torch.float16, "_f16")])
 def test_ddim_inversion_matches_reference_golden(tmp_path, monkeypatch, dtype, sfx):
     """Row f4: `tokenflow_amd.inversion.ddim_inversion` / `ddim_sample` (latent update through the oracle-backed
