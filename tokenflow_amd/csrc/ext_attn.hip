@@ -1201,7 +1201,16 @@ struct IlSchedule {   // MFMA order of one phase: QK^T k-steps (one accumulator 
     }
 };
 
-template <typename T, int DH, int NW, int MODE, int MINW>
+// DMA = true (round 5, non-PACK forms; A/B switch TF_TUNE_IL40_DMA, OFF: correct -- 268 attention tests -- and 0.5 %
+// SLOWER than register staging at cfg2 level 0, profiles/r05_attn_il40_dma_ab.txt: the loop is bound by the VALU issue
+// port, not by its staging): K and V^T tiles go global -> LDS by `global_load_lds_dwordx4` instead of through
+// registers: no staging VGPRs, no ds_write pass, 10 DMA instructions per workgroup and tile instead of 32 loads + writes.
+// The DMA writes lane-linearly, so the images are dense: K rows of DH elements (the QK^T k-step that straddles DH reads
+// the next row's first elements against ZERO columns of Q; 80-B rows are bank-conflict-free as they are), V^T rows of 64
+// keys whose 16-B pieces are XOR-swizzled with (row & 7) on the DMA's source address and on the fragment read.  A tile is
+// issued right behind the barrier that frees its buffer and drained (vmcnt(0)) in front of the next one: the same
+// distance the register staging had.
+template <typename T, int DH, int NW, int MODE, int MINW, bool DMA = false>
 __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p) {
     typedef AttnCfg<DH, 64> C;
     typedef typename T::elem E;
@@ -1216,9 +1225,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     static_assert(!PACK || DH == 40, "the packed dual-V image is a Dh = 40 form");
     constexpr int VR = PACK ? 2 * DH : DH;              // staged V^T rows per tile
     constexpr int MT = PACK ? 3 : C::MT;                // P.V M-tiles
-    constexpr int V_ELEMS = MT * 32 * C::VROW;
+    static_assert(!DMA || (!PACK && (64 * DH * 2) % 1024 == 0 && (VR * 128) % 1024 == 0), "DMA form: whole 1 KB pieces");
+    constexpr int KROW = DMA ? DH : C::KROW;            // LDS row strides (elements): dense images in the DMA form
+    constexpr int VROW = DMA ? 64 : C::VROW;
+    constexpr int K_ELEMS = 64 * KROW;
+    constexpr int V_ELEMS = MT * 32 * VROW;
     constexpr int NPK = C::npk(NT), NPV = (VR * 8 + NT - 1) / NT;
-    constexpr int BUF_ELEMS = C::K_ELEMS + V_ELEMS;
+    constexpr int BUF_ELEMS = K_ELEMS + V_ELEMS;
     constexpr bool ONES = (VR % 32) != 0;   // denominator from the MFMA (row VR of the V^T image = 1.0)
     constexpr int ONES_R = ((VR % 32) & 3) + 4 * ((VR % 32) >> 3);
     static_assert(!ONES || ((VR % 32) & 4) == 0, "the ones row must live in lane half 0");
@@ -1227,7 +1240,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     auto sK = [&](int buf) { return reinterpret_cast<E*>(smem) + buf * BUF_ELEMS; };
-    auto sV = [&](int buf) { return reinterpret_cast<E*>(smem) + buf * BUF_ELEMS + C::K_ELEMS; };
+    auto sV = [&](int buf) { return reinterpret_cast<E*>(smem) + buf * BUF_ELEMS + K_ELEMS; };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1277,7 +1290,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     for (int id = tid; id < 2 * BUF_ELEMS / 8; id += NT) st16(reinterpret_cast<E*>(smem) + id * 8, u32x4{0, 0, 0, 0});
     __syncthreads();
     if constexpr (ONES)
-        for (int id = tid; id < 2 * 64; id += NT) sV(id >> 6)[VR * C::VROW + (id & 63)] = (E)1.f;
+        for (int id = tid; id < 2 * 64; id += NT) sV(id >> 6)[VR * VROW + (id & 63)] = (E)1.f;
 
     // ---- Q fragments
     const int q_row = qt * (32 * NW) + wave * 32 + l31;
@@ -1317,14 +1330,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     for (int i = 0; i < NPK; ++i) {
         const int id = min(tid + NT * i, 64 * C::PPR - 1);
         k_goff[i] = (id / C::PPR) * (int)p.ld + (id % C::PPR) * 8;
-        k_loff[i] = (id / C::PPR) * C::KROW + (id % C::PPR) * 8;
+        k_loff[i] = (id / C::PPR) * KROW + (id % C::PPR) * 8;
     }
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
         const int id = min(tid + NT * i, VR * 8 - 1);
         const int row = id >> 3;   // image row: bank row / DH (the next branch's rows lie H*DH image rows further), feature row % DH
         v_goff[i] = ((row / DH) * H * DH + row % DH) * (int)vt_row + (id & 7) * 8;
-        v_loff[i] = row * C::VROW + (id & 7) * 8;
+        v_loff[i] = row * VROW + (id & 7) * 8;
     }
     const int v_wrap = p.Spad - (tpf - 1) * 64;
     const int64_t k_wrap_off = p.k_fs - (int64_t)(tpf - 1) * 64 * p.ld;
@@ -1355,6 +1368,51 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
         for (int i = 0; i < NPV; ++i)
             if (tid + NT * i < VR * 8) st16(sV(buf) + v_loff[i], rv[i]);
     };
+    // DMA form: piece q of a tile pair = 1 KB of the K image (q < NKP) or of the V^T image; wave w issues q = w, w + NW, ..
+    constexpr int NKP = DMA ? 64 * DH * 2 / 1024 : 0, NVP = DMA ? VR * 128 / 1024 : 0;
+    constexpr int NSLOT = DMA ? (NKP + NVP + NW - 1) / NW : 1;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int d_goff[NSLOT];
+    if constexpr (DMA) {
+#pragma unroll
+        for (int n = 0; n < NSLOT; ++n) {
+            const int q = wave_u + NW * n;
+            if (q < NKP) {
+                const int o = q * 1024 + lane * 16;
+                const int row = o / (2 * DH);
+                d_goff[n] = row * (int)p.ld + ((o - row * 2 * DH) >> 1);
+            } else {
+                const int o = (q - NKP) * 1024 + lane * 16;
+                const int row = o >> 7, sl = (o & 127) >> 4;
+                d_goff[n] = row * (int)vt_row + ((sl ^ (row & 7)) << 3);
+            }
+        }
+    }
+    auto dma_k = [&](int buf) {      // the next K tile -> Kbuf[buf]
+#pragma unroll
+        for (int n = 0; n < NSLOT; ++n) {
+            const int q = wave_u + NW * n;
+            if (q < NKP)
+                __builtin_amdgcn_global_load_lds((glb_ptr)(k_next + d_goff[n]), (lds_ptr)(sK(buf) + q * 512), 16, 0, 0);
+        }
+        const bool wrap = k_tt == tpf - 1;
+        k_next += wrap ? k_wrap_off : (int64_t)64 * p.ld;
+        k_tt = wrap ? 0 : k_tt + 1;
+    };
+    auto dma_v = [&](int buf) {      // the next V^T tile -> Vbuf[buf]
+#pragma unroll
+        for (int n = 0; n < NSLOT; ++n) {
+            const int q = wave_u + NW * n;
+            if (q >= NKP && q < NKP + NVP)
+                __builtin_amdgcn_global_load_lds((glb_ptr)(v_next + d_goff[n]), (lds_ptr)(sV(buf) + (q - NKP) * 512), 16, 0, 0);
+        }
+        const bool wrap = v_tt == tpf - 1;
+        v_next += wrap ? v_wrap : 64;
+        v_tt = wrap ? 0 : v_tt + 1;
+    };
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
     f32x16 o[MT], s[2];
     vec8 pf[2][2];      // P of the two 32-key halves, two 16-key k-steps each
@@ -1445,10 +1503,15 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
             const float mc = m_run * c;
             mc2 = f32x2{mc, mc};
         }
-        const E* vbase = sV(vbuf) + l31 * C::VROW + Hh * 32 + 8 * hi;
-        const E* kbase = sK(kbuf) + (Hh * 32 + l31) * C::KROW + 8 * hi;
+        const E* vbase = sV(vbuf) + l31 * VROW + (DMA ? 0 : Hh * 32 + 8 * hi);
+        const E* kbase = sK(kbuf) + (Hh * 32 + l31) * KROW + 8 * hi;
+        const int vswz = l31 & 7;   // DMA form: 16-B piece index of row (32 a + l31) is XOR-ed with row & 7
         auto frag = [&](int i) -> vec8 {
-            if (sch.is_pv[i]) return __builtin_bit_cast(vec8, ld16(vbase + sch.a[i] * 32 * C::VROW + 16 * sch.b[i]));
+            if (sch.is_pv[i]) {
+                if constexpr (DMA)
+                    return __builtin_bit_cast(vec8, ld16(vbase + sch.a[i] * 32 * VROW + (((4 * Hh + hi + 2 * sch.b[i]) ^ vswz) << 3)));
+                return __builtin_bit_cast(vec8, ld16(vbase + sch.a[i] * 32 * VROW + 16 * sch.b[i]));
+            }
             return __builtin_bit_cast(vec8, ld16(kbase + 16 * sch.a[i]));
         };
         constexpr int PF = 2;   // fragment reads run PF steps ahead of their MFMA (3 at Dh = 40: 132 VGPRs, one workgroup per CU)
@@ -1490,15 +1553,22 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     typedef std::false_type No;
 
     // ---- prologue: K(0) -> Kbuf[0]; S(0) = K(0) Q; P0(0); registers <- K(1), V(0)
-    load_k();
-    __syncthreads();            // LDS init done before the first staging write
-    write_k(0);
-    if (ntiles > 1) load_k();   // K(1)
-    load_v();                   // V(0)
-    __syncthreads();
+    if constexpr (DMA) {
+        __syncthreads();        // LDS init done before the first DMA lands
+        dma_k(0);               // K(0)
+        dma_wait();
+        __syncthreads();
+    } else {
+        load_k();
+        __syncthreads();            // LDS init done before the first staging write
+        write_k(0);
+        if (ntiles > 1) load_k();   // K(1)
+        load_v();                   // V(0)
+        __syncthreads();
+    }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-        const E* krow = sK(0) + (kt * 32 + l31) * C::KROW + 8 * hi;
+        const E* krow = sK(0) + (kt * 32 + l31) * KROW + 8 * hi;
 #pragma unroll
         for (int t = 0; t < C::KS; ++t)
             s[kt] = T::mfma32(__builtin_bit_cast(vec8, ld16(krow + 16 * t)), qf[t], t == 0 ? zero : s[kt]);
@@ -1517,8 +1587,23 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     // All tiles but the last: every phase also runs the QK^T half of the NEXT tile.  The last tile is peeled (no
     // branch on "is there a next tile" inside the loop: the two shapes of the body would otherwise make the
     // compiler keep two copies of the O accumulators and copy between them).
+    if constexpr (DMA) {
+        // Kbuf[1] and Vbuf[0] hold nothing yet: K(1), V(0) may be issued at once (every wave is past the LDS init)
+        if (ntiles > 1) dma_k(1);
+        dma_v(0);
+    }
     for (int t = 0; t + 1 < ntiles; ++t) {
         const int cur = t & 1, nxt = cur ^ 1;
+        if constexpr (DMA) {
+            dma_wait();                   // this wave's pieces of K(t+1), V(t) have landed ...
+            __syncthreads();              // ... everybody's have; every wave has left iteration t-1, whose phases were the
+            __builtin_amdgcn_sched_barrier(0);   // last readers of Kbuf[cur] (K(t)) and Vbuf[nxt] (V(t-1)): free to refill
+            if (t + 2 < ntiles) dma_k(cur);      // K(t+2)
+            dma_v(nxt);                          // V(t+1)
+            phase(H0{}, Yes{}, Yes{}, cur, nxt);
+            phase(H1{}, Yes{}, Yes{}, cur, nxt);
+            continue;
+        }
         // Kbuf[nxt] held K(t-1) (last read by QK(t-1) in iteration t-2), Vbuf[cur] held V(t-2) (last read in iteration
         // t-2): every wave has passed the barrier of iteration t-1, which follows iteration t-2 -> free to overwrite.
         write_k(nxt);                 // K(t+1)
@@ -1532,7 +1617,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     }
     {
         const int cur = (ntiles - 1) & 1;
-        write_v(cur);                 // V(n-1)
+        if constexpr (DMA) dma_wait();
+        else write_v(cur);            // V(n-1)
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
         phase(H0{}, No{}, Yes{}, cur, cur);    // O += V0 P0   ||  P1
@@ -1593,12 +1679,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     }
 }
 
-template <typename T, int DH, int NW, int MODE, int MINW>
+template <typename T, int DH, int NW, int MODE, int MINW, bool DMA = false>
 int launch_il(AttnParams p, hipStream_t st) {
     typedef AttnCfg<DH, 64> C;
-    constexpr size_t lds = MODE == MODE_DUAL ? 2 * (size_t)(C::K_ELEMS + 96 * C::VROW) * 2   // packed dual-V image
-                                             : C::lds_bytes(1);
-    auto kern = ext_attn_il_kernel<T, DH, NW, MODE, MINW>;
+    constexpr size_t lds = DMA                 ? 2 * (size_t)(64 * DH + C::MT * 32 * 64) * 2 + 16   // dense images (+ the K over-read)
+                           : MODE == MODE_DUAL ? 2 * (size_t)(C::K_ELEMS + 96 * C::VROW) * 2        // packed dual-V image
+                                               : C::lds_bytes(1);
+    auto kern = ext_attn_il_kernel<T, DH, NW, MODE, MINW, DMA>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     p.nQT = (p.S + 32 * NW - 1) / (32 * NW);
@@ -1704,6 +1791,17 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
                             (int64_t)3 * p.Kq * ((p.S + 255) / 256) * p.H * p.nseg >= TF_TUNE_IL40_MIN_WGS;
 #else
             const bool il = false;
+#endif
+#ifdef TF_TUNE_IL40_DMA
+            if (il)
+                return compose([&] { return launch_il<T, 40, 8, MODE_ALL, 4, true>(p, st); },
+                               [&] {
+#ifndef TF_TUNE_NO_IL40_DUAL
+                                   if (p.S >= 256 && p.S % 64 == 0) return launch_il<T, 40, 4, MODE_DUAL, 3>(p, st);
+#endif
+                                   return launch_one<T, DH, 1, 4, MODE_DUAL, 3, false>(p, st);
+                               },
+                               [&] { return launch_il<T, 40, 8, MODE_SOURCE, 4, true>(p, st); });
 #endif
             return compose([&] {
 #ifdef TF_TUNE_IL40_NW4_SMALL

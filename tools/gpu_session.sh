@@ -52,6 +52,9 @@ for stage in "$@"; do
                   TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/prop_microbench.py 8,5,1024,640 10,8,2304,640 25,8,1024,640 10,8,576,1280 4,2,1024,320 2>/dev/null | grep "one call" | tee -a $O/nn_glds_spread_ab.txt
                   TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/nn_microbench.py 8,5,1024,640 2>/dev/null | tee -a $O/nn_glds_spread_ab.txt; done
                 timeout 600 python -m pytest tests/test_fullsize_gpu.py tests/test_kernels_gpu.py -q --tb=short -p no:cacheprovider -k "lds_dma or nn_search or propagat" 2>&1 | tail -3 | tee -a $O/nn_glds_spread_ab.txt ;;
+    il40dma)    for lib in "" il40dma "" il40dma; do echo "== lib=${lib:-current}" | tee -a $O/attn_il40_dma_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 8,4096,8,40 4,1024,8,40 2>/dev/null | tee -a $O/attn_il40_dma_ab.txt; done
+                TOKENFLOW_HIP_LIB=build/variants/lib_il40dma.so timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_fullsize_gpu.py tests/test_baseline_configs_gpu.py -q --tb=short -p no:cacheprovider -k "attn" 2>&1 | tail -6 | tee -a $O/attn_il40_dma_ab.txt ;;
     trprobe)    timeout 60 tools/ubench/tr_probe > $O/tr_probe.txt 2>&1; cat $O/tr_probe.txt ;;
     fusedtests) timeout 900 python -m pytest tests/test_fused_attn_gpu.py -q --tb=line -p no:cacheprovider 2>&1 | tail -40 > $O/fused_tests.txt; tail -25 $O/fused_tests.txt ;;
     kerneltests) timeout 1500 python -m pytest tests/test_kernels_gpu.py -q --tb=line -p no:cacheprovider -k "attn" 2>&1 | tail -30 > $O/kernel_attn_tests.txt; tail -15 $O/kernel_attn_tests.txt ;;
