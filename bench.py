@@ -40,7 +40,10 @@ Prints ONE JSON line (rank 0):
   input_sets    step i runs on input set i % n; set s, block b is seeded 1234 + 16 s + b; all sets are
                 generated before the timed region (up to 8, at most 64 GB).
   roofline_other  NN search (MFMA roof) and gather/blend (HBM roof) on one level-0 chunk, HIP events, after the timed
-                region (rank 0, N = 1).
+                region (rank 0, N = 1); since round 6 also ONE level-0 attention launch of BASELINE configs 4 and 5 (head
+                dim 64) against the MFMA roof.
+  other_configs   ms per step of BASELINE config 1's geometry (3 eager steps after the timed region, rank 0, N = 1).
+  value_bit_identical / value_split   N > 1: frames/s of each timed form, whatever `value` picked (`value_form`).
   yardstick     same box, same run, after the timed region (rank 0, N = 1): what the vendor libraries reach -- hipBLASLt
                 (torch.matmul, bf16 8192^3) and PyTorch-ROCm's fused attention (aotriton flash behind
                 scaled_dot_product_attention) on the level-0 bank problems.  Comparison points for the roofline
@@ -108,6 +111,8 @@ def parse():
                          "from manual_seed(1234 + 16 s + b)); 0 = auto: one per step, at most 8, at most 64 GB in total")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-yardstick", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the cfg4 / cfg5 level-0 launches and the cfg1 steps that follow the headline's timed region")
     ap.add_argument("--cpu-sample-levels", default="0,1,2,3")
     return ap.parse_args()
 
@@ -267,6 +272,69 @@ def other_rooflines(cfg, blocks, w):
          "frac": round(by / t_gb / 1e6 / 8000.0, 4), "avg_launch_ms": round(t_gb, 4),
          "algorithmic_mbytes_per_launch": round(by / 1e6, 1)},
     ]
+
+
+def other_config_rooflines(dev):
+    """Driver-visible numbers for the configurations that are not the headline, after the timed
+    region (rank 0, N = 1), on seeded synthetic tensors: ONE level-0 extended-attention launch of BASELINE configs 4 and 5
+    (head dim 64: K = 10, S = 9216 and K = 25, S = 4096, 5 heads) against the MFMA roof with SURVEY 8(d)'s algorithmic flops,
+    HIP events on the launch stream around the second of two launches (pre-pass included).  ~0.3 s of box time."""
+    res = []
+    for name in ("cfg4", "cfg5"):
+        cfg = workload.CONFIGS[name]
+        S, D, h = cfg.levels[0]
+        K = cfg.K
+        try:
+            g = torch.Generator(device=dev).manual_seed(4321)
+            q, k, v = (torch.randn(3 * K, S, D, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+                       for _ in range(3))
+            fn = lambda: ops.ext_attn(q, k, v, h, (D // h) ** -0.5, False)  # noqa: E731
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            fl = workload.attn_flops(K, S, D)
+            res.append({"kernel": "tf_ext_attn_fwd, %s level 0 (K = %d, S = %d, %d heads of %d), no q/k injection, one launch "
+                                  "(+ V^T pre-pass)" % (name, K, S, h, D // h),
+                        "bound": "mfma", "achieved": round(fl / ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac": round(fl / ms / 1e9 / 2500.0, 4), "avg_launch_ms": round(ms, 3), "launches_timed": 1,
+                        "algorithmic_gflop_per_launch": round(fl / 1e9, 1)})
+            del q, k, v
+        except Exception as e:  # noqa: BLE001
+            res.append({"kernel": "tf_ext_attn_fwd, %s level 0" % name, "error": str(e)[:160]})
+    torch.cuda.empty_cache()
+    return res
+
+
+def other_config_steps(dev, w_of):
+    """ms per step of BASELINE config 1's geometry (8 frames, 256^2, 4 keyframes: launch-bound), 2 warm-up + 3 timed eager
+    steps, same `run_step` as the headline."""
+    out = {}
+    for name, steps in (("cfg1", 3),):
+        cfg = workload.CONFIGS[name]
+        try:
+            sh = sharded.FrameShard(cfg.K, attn_split=False)
+            gen = torch.Generator(device=dev).manual_seed(1234)
+            blocks = [Block(cfg, lvl, inj, sh, gen, dev) for lvl, inj in workload.BLOCKS]
+            w = w_of(cfg.chunk)
+            for i in range(2):
+                run_step(cfg, blocks, sh, i % 2 == 0, w)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for i in range(steps):
+                run_step(cfg, blocks, sh, i % 2 == 0, w)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / steps
+            out[name] = {"ms_per_step": round(ms, 4), "frames_per_s": round(cfg.frames / (ms * 1e-3), 1), "steps": steps,
+                         "workload": cfg.name, "launch": "eager"}
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": str(e)[:160]}
+    return out
 
 
 def power_state(blocks):
@@ -823,6 +891,9 @@ def main():
         "ms_per_step_split": ms_split and round(ms_split, 3),
         "ms_per_step_bit_identical": round(ms_bit, 3) if world > 1 else None,
         "value_form": value_form if world > 1 else "single GPU",
+        # fixed-form fields (like-for-like across rounds whatever `value` picked): frames/s of each timed form
+        "value_bit_identical": round(cfg.frames / (ms_bit * 1e-3), 2) if world > 1 else None,
+        "value_split": round(cfg.frames / (ms_split * 1e-3), 2) if ms_split else None,
         "ms_per_step_inject_on": avg(per_state[True]) and round(avg(per_state[True]), 3),
         "ms_per_step_inject_off": avg(per_state[False]) and round(avg(per_state[False]), 3),
         "config": {"workload": cfg.name + " (hot path: 16 blocks x [ext-attn + NN-search + gather/blend over %d chunks])" % cfg.K,
@@ -849,6 +920,11 @@ def main():
             out["parity"] = parity_check(cfg, blocks, w)
         if world == 1 and not args.no_parity:
             out["roofline_other"] = other_rooflines(cfg, blocks, w)
+        if world == 1 and not args.no_other_configs and args.config == "cfg2":
+            del input_sets[1:]              # the rotating input sets are no longer needed: room for the cfg4 / cfg5 tensors
+            torch.cuda.empty_cache()
+            out.setdefault("roofline_other", []).extend(other_config_rooflines(dev))
+            out["other_configs"] = other_config_steps(dev, lambda n: blend_w(n, dev))
         if world == 1 and not args.no_yardstick:
             out["yardstick"] = yardstick(cfg)
             out["yardstick"]["power_state"] = power_state(blocks)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TF_ABI_VERSION 6
+#define TF_ABI_VERSION 7
 
 /* Every entry point below is exported with default visibility; the library itself is built with -fvisibility=hidden, so
  * its exported symbols are exactly the declarations of this header (checked by tests/test_hooks_cpu.py). */
@@ -169,6 +169,8 @@ TF_API int tf_head_unpack(const void* recv, void* const* dsts, const int64_t* fr
  *   first maximal j wins (torch.argmax).  The 1/||tgt[t]|| factor of util.py:66
  *   is a positive per-row constant and cannot change the argmax, so targets are
  *   never normalised.  idx is int32 [P, n_tgt].  D multiple of 8; dtype bf16/f16.
+ *   tgt, piv, ws AND inv_norm 16-byte aligned (TF_ERR_ALIGN otherwise; the same holds for the tf_nn_gather_blend*
+ *   forms): the LDS-DMA search kernel fetches the inverse norms of a pivot tile in 16-byte pieces.
  *   ws: scratch for per-split candidates when the pivot range is split over workgroups
  *   (size from tf_nn_search_workspace_bytes, >= 256 bytes).
  * ------------------------------------------------------------------------ */
@@ -364,6 +366,13 @@ TF_API int tf_comm_init_loopback(int rank, int world, tf_comm** comm_out);
 /* loopback only: enabled = 0 makes every exchange a no-op (nothing moves, nothing is enqueued) -- the rank's launch sequence
  * with the stand-in copies taken out of the timing as well; buffers that an exchange would have filled keep their contents */
 TF_API int tf_comm_loopback_copies(tf_comm* comm, int enabled);
+/* loopback only (ABI 7): a wire MODEL.  Behind its copies (if enabled) every exchange enqueues, on the stream it was issued
+ * on, a one-wave kernel that holds the stream for  latency_us + bytes_on_the_busiest_link / (gbps_per_link GB/s):  the
+ * schedule's overlap of exchanges with compute is then EXECUTED, not estimated (tools/rank_step_microbench.py
+ * --wire-model).  Links are full duplex and point to point (xGMI): an all-to-all or all-gather puts the rows for / from
+ * peer p on the link to p, the busiest link carries max_p max(sent_p, received_p) bytes; a neighbour exchange sends on
+ * one link and receives on another.  latency_us <= 0 and gbps_per_link <= 0 switch the model off (the default). */
+TF_API int tf_comm_loopback_wire(tf_comm* comm, double latency_us, double gbps_per_link);
 TF_API int tf_comm_destroy(tf_comm* comm);
 TF_API int tf_comm_rank(const tf_comm* comm);
 TF_API int tf_comm_world(const tf_comm* comm);

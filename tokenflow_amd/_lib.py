@@ -21,7 +21,7 @@ def attn_hint(qw: int = 0, kw: int = 0, qb: int = 1) -> int:
     return (code[qw] << 8) | (code[kw] << 11) | (TF_ATTN_HINT_QB2 if qb == 2 else 0)
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 TF_RANK_HEADS, TF_RANK_BANK, TF_RANK_SLOTS, TF_RANK_NO_HALO, TF_RANK_INV_NORM = 0, 1, 64, 16, 32
 TF_ERR_COMM = -6
 
@@ -72,6 +72,7 @@ _SIGNATURES = {
     "tf_comm_init_hooks": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p]),
     "tf_comm_init_loopback": (_c.c_int, [_c.c_int, _c.c_int, _c.c_void_p]),
     "tf_comm_loopback_copies": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "tf_comm_loopback_wire": (_c.c_int, [_c.c_void_p, _c.c_double, _c.c_double]),
     # one rank's pivotal pass of a block in one call (csrc/rank_exec.hip; tokenflow_amd/sharded.py NativeShard)
     "tf_rank_create": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p]),
     "tf_rank_destroy": (_c.c_int, [_c.c_void_p]),

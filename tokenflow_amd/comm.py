@@ -66,16 +66,20 @@ class HipComm:
         self._h, self.rank, self.world = h, rank, world
 
     @classmethod
-    def loopback(cls, rank: int, world: int, copies: bool = True) -> "HipComm":
+    def loopback(cls, rank: int, world: int, copies: bool = True, wire=None) -> "HipComm":
         """The wire-less stand-in (tf_comm_init_loopback): every exchange becomes device-to-device copies of the sizes a
         rank of a `world`-GPU run receives, out of this rank's own buffers.  For timing one rank's launch sequence on
-        one GPU (tools/rank_step_microbench.py); the received data is meaningless for world > 1."""
+        one GPU (tools/rank_step_microbench.py); the received data is meaningless for world > 1.
+        `wire = (latency_us, gbps_per_link)`: the wire MODEL (tf_comm_loopback_wire) -- every exchange also holds its
+        stream for latency + bytes on its busiest link / bandwidth, so that the schedule's overlap is executed."""
         self = cls.__new__(cls)
         h = ctypes.c_void_p()
         _lib.check(_lib.load().tf_comm_init_loopback(rank, world, ctypes.byref(h)), "tf_comm_init_loopback")
         self._h, self.rank, self.world = h, rank, world
         if not copies:      # the exchanges enqueue nothing at all: the stand-in copies out of the timing too
             _lib.check(_lib.load().tf_comm_loopback_copies(h, 0), "tf_comm_loopback_copies")
+        if wire is not None:
+            _lib.check(_lib.load().tf_comm_loopback_wire(h, float(wire[0]), float(wire[1])), "tf_comm_loopback_wire")
         return self
 
     @classmethod

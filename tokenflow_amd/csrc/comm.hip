@@ -71,6 +71,7 @@ struct tf_comm {
     int kind = COMM_RCCL;
     tf_comm_hooks hooks = {};
     bool copies = true;   // loopback only: false = the exchanges move nothing at all (tf_comm_loopback_copies)
+    double wire_lat_us = 0.0, wire_gbps = 0.0;   // loopback only: the wire model (tf_comm_loopback_wire); 0 = off
 };
 
 namespace {
@@ -85,6 +86,24 @@ int copy_async(void* dst, const void* src, size_t bytes, hipStream_t st, const c
     return 0;
 }
 
+// Wire model of the loopback transport: one wave that holds the stream for `ticks` of the constant 100 MHz clock
+// (s_memrealtime) -- what an exchange of that duration does to the schedule, without its data.  One wave on one CU: the
+// compute streams beside it lose nothing measurable.
+__global__ void wire_hold_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+int wire_hold(const tf_comm* c, size_t busiest_link_bytes, hipStream_t st, const char* what) {
+    if (c->wire_lat_us <= 0.0 && c->wire_gbps <= 0.0) return 0;
+    double us = c->wire_lat_us > 0.0 ? c->wire_lat_us : 0.0;
+    if (c->wire_gbps > 0.0) us += (double)busiest_link_bytes / (c->wire_gbps * 1e3);   // GB/s = 1e3 bytes per us
+    const unsigned long long ticks = (unsigned long long)(us * 100.0 + 0.5);           // wall_clock64: 100 MHz
+    if (ticks == 0) return 0;
+    hipLaunchKernelGGL(wire_hold_kernel, dim3(1), dim3(64), 0, st, ticks);
+    TF_LAUNCH_CHECK(what);
+    return 0;
+}
+
 // loopback forms: one copy per message a real rank would receive, of that message's size, from this rank's own data
 int loop_allgather_rows(const tf_comm* c, const void* local, void* bank, const int64_t* rows, size_t rb, hipStream_t st) {
     char* r = static_cast<char*>(bank);
@@ -94,14 +113,27 @@ int loop_allgather_rows(const tf_comm* c, const void* local, void* bank, const i
         if (const int rc = copy_async(r, local, n < mine ? n : mine, st, "tf_allgather_rows(loopback)", c->copies)) return rc;
         r += n;
     }
-    return 0;
+    size_t link = 0;   // the link to peer p carries this rank's rows out and p's rows in (full duplex)
+    for (int p = 0; p < c->world; ++p)
+        if (p != c->rank) {
+            const size_t in = (size_t)rows[p] * rb, io = in > mine ? in : mine;
+            link = io > link ? io : link;
+        }
+    return wire_hold(c, link, st, "tf_allgather_rows(loopback wire)");
 }
 
 int loop_all_to_all(const tf_comm* c, const void* send, void* recv, const int64_t* send_rows, const int64_t* recv_rows,
                     size_t rb, hipStream_t st) {
     size_t ns = 0, nr = 0;
     for (int p = 0; p < c->world; ++p) ns += (size_t)send_rows[p] * rb, nr += (size_t)recv_rows[p] * rb;
-    return copy_async(recv, send, ns < nr ? ns : nr, st, "tf_all_to_all_rows(loopback)", c->copies);
+    if (const int rc = copy_async(recv, send, ns < nr ? ns : nr, st, "tf_all_to_all_rows(loopback)", c->copies)) return rc;
+    size_t link = 0;   // the link to peer p carries the rows for p out and the rows from p in (full duplex)
+    for (int p = 0; p < c->world; ++p)
+        if (p != c->rank) {
+            const size_t out = (size_t)send_rows[p] * rb, in = (size_t)recv_rows[p] * rb, io = out > in ? out : in;
+            link = io > link ? io : link;
+        }
+    return wire_hold(c, link, st, "tf_all_to_all_rows(loopback wire)");
 }
 
 }  // namespace
@@ -189,6 +221,13 @@ extern "C" int tf_comm_init_loopback(int rank, int world, tf_comm** comm_out) {
 extern "C" int tf_comm_loopback_copies(tf_comm* comm, int enabled) {
     TF_ARG(comm && comm->kind == COMM_LOOPBACK, TF_ERR_COMM, "tf_comm_loopback_copies: not a loopback communicator");
     comm->copies = enabled != 0;
+    return 0;
+}
+
+extern "C" int tf_comm_loopback_wire(tf_comm* comm, double latency_us, double gbps_per_link) {
+    TF_ARG(comm && comm->kind == COMM_LOOPBACK, TF_ERR_COMM, "tf_comm_loopback_wire: not a loopback communicator");
+    comm->wire_lat_us = latency_us > 0.0 ? latency_us : 0.0;
+    comm->wire_gbps = gbps_per_link > 0.0 ? gbps_per_link : 0.0;
     return 0;
 }
 
@@ -316,7 +355,13 @@ extern "C" int tf_sendrecv_pivot(tf_comm* comm, const void* const* send, const i
                 const size_t n = (size_t)(recv_elems[i] < send_elems[i] ? recv_elems[i] : send_elems[i]) * eb;
                 if (const int rc = copy_async(recv[i], send[i], n, st, "tf_sendrecv_pivot(loopback)", comm->copies)) return rc;
             }
-        return 0;
+        size_t out = 0, in = 0;   // one link to the right neighbour, another from the left one
+        if (send_peer >= 0)
+            for (int i = 0; i < n_send; ++i) out += (size_t)send_elems[i] * eb;
+        if (recv_peer >= 0)
+            for (int i = 0; i < n_recv; ++i) in += (size_t)recv_elems[i] * eb;
+        if (out == 0 && in == 0) return 0;
+        return wire_hold(comm, out > in ? out : in, st, "tf_sendrecv_pivot(loopback wire)");
     }
     TF_NEED_RCCL("tf_sendrecv_pivot");
     TF_NCCL(R.GroupStart(), "tf_sendrecv_pivot");

@@ -67,6 +67,16 @@ struct AttnCfg {
 
 enum { MODE_ALL = 0, MODE_SOURCE = 1, MODE_DUAL = 2 };
 
+// Head dims whose streaming kernels use the Cauchy-Schwarz score bound |q.k| <= |q| max|k| (per-block key norms from the
+// pre-pass) to skip the per-tile maximum: Dh = 40 since round 2, Dh = 64 since round 6 (A/B switch TF_TUNE_NO_BOUND64).
+constexpr bool attn_has_bound(int dh) {
+#ifdef TF_TUNE_NO_BOUND64
+    return dh == 40;
+#else
+    return dh == 40 || dh == 64;
+#endif
+}
+
 struct AttnParams {
     const void* q;
     const void* k;
@@ -245,7 +255,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_kernel(AttnParams p) {
     // FOLD_T binades; P = exp2((s - m_run) c) may then exceed 1 (<= 2^FOLD_T), numerator and denominator see the
     // same P.  Saves the 16 v_max3 + permlane of most tiles and most O rescales.
     //   Measured (round 2, cfg2 level 0, fp32 scaling): 4.25 -> 4.03 ms with the bound; the folded form is 3.58 ms.
-    constexpr bool BOUND = DH == 40;
+    constexpr bool BOUND = attn_has_bound(DH);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     auto sK = [&](int buf) { return reinterpret_cast<E*>(smem) + buf * BUF_ELEMS; };
@@ -830,6 +840,8 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
     constexpr bool FOLD = FQ && ONES && (C::DKP > DH);
     constexpr int SH_T = DH / 16, SH_HI = (DH % 16) / 8;
     constexpr float FOLD_T = 8.0f;
+    constexpr bool BOUND = attn_has_bound(DH);
+    constexpr float BOUND_T = std::is_same<E, _Float16>::value ? 14.0f : 60.0f;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     auto sK = [&](int buf) { return reinterpret_cast<E*>(smem) + buf * BUF_ELEMS; };
@@ -897,6 +909,27 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) qf[qi][t][j] = (E)((float)qf[qi][t][j] * p.c);
             }
+        }
+    }
+
+    float s_bound[2] = {0.f, 0.f};   // BOUND: upper bound of q.k*c (log2 units) over every key this problem sees
+    if constexpr (BOUND && !FOLD) {
+        const int ppf = p.Spad / 64;
+        const float* part = p.knorm2 + ((int64_t)(bq * H + h) * K + f_lo) * ppf;
+        float kn2 = 0.f;
+        for (int i = lane; i < n_fr * ppf; i += 64) kn2 = fmaxf(kn2, part[i]);
+#pragma unroll
+        for (int o_ = 32; o_ > 0; o_ >>= 1) kn2 = fmaxf(kn2, __shfl_xor(kn2, o_));
+        const float kn = __builtin_sqrtf(kn2) * 1.001f * p.c;
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            float q2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < C::KS; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) q2 = fmaf((float)qf[qi][t][j], (float)qf[qi][t][j], q2);
+            q2 += __shfl_xor(q2, 32);
+            s_bound[qi] = __builtin_sqrtf(q2) * kn;
         }
     }
 
@@ -1011,12 +1044,34 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
                         if (tt * 64 + kt * 32 + cd_row(r, hi) >= S) s[qi][kt][r] = -INFINITY;
             }
         }
-        float mx = s[qi][0][0];
+        auto tile_max = [&]() {
+            float mx = s[qi][0][0];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qi][kt][r]);
-        mx = max_with_lane_xor32(mx);
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qi][kt][r]);
+            return max_with_lane_xor32(mx);
+        };
+        if constexpr (BOUND && !FOLD) {
+            // deferred shift under the score bound (see BOUND in ext_attn_kernel): the tile maximum is looked at only
+            // while the bound does not exclude an overflow; m_run = -inf before the first tile, which always looks
+            if (__any(s_bound[qi] - m_run[qi] * c > BOUND_T)) {
+                const float mx = tile_max();
+                const bool over = (mx - m_run[qi]) * c > BOUND_T;
+                if (__any(over)) {
+                    const float m_new = over ? mx : m_run[qi];
+                    const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);   // exp2(-inf) = 0 on tile 0 (O = 0)
+                    m_run[qi] = m_new;
+                    if constexpr (!ONES) l_run[qi] *= alpha;
+#pragma unroll
+                    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[qi][mt][r] *= alpha;
+                }
+            }
+            return m_run[qi] * c;
+        }
+        const float mx = tile_max();
         if constexpr (FOLD) {
             // s already is score*c - shift: move the shift only on the first tile or when the tile maximum
             // exceeds it by more than FOLD_T (wave-uniform branch)
@@ -1060,7 +1115,10 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
         constexpr int X = decltype(x_c)::value;
         constexpr int Y = 1 - X;
         constexpr PpSchedule<C::MT, C::KS> sch{};
-        constexpr int PF = 4;             // fragment reads run PF steps ahead of their MFMA (LDS latency)
+#ifndef TF_TUNE_PP_PF
+#define TF_TUNE_PP_PF 4
+#endif
+        constexpr int PF = TF_TUNE_PP_PF;   // fragment reads run PF steps ahead of their MFMA (LDS latency)
         float lsum = 0.f;
         const E* vbase = sV(vbuf) + l31 * C::VROW + 8 * hi;
         const E* kbase = sK(kbuf) + l31 * C::KROW + 8 * hi;
@@ -1201,16 +1259,20 @@ struct IlSchedule {   // MFMA order of one phase: QK^T k-steps (one accumulator 
     }
 };
 
-// DMA = true (round 5, non-PACK forms; A/B switch TF_TUNE_IL40_DMA, OFF: correct -- 268 attention tests -- and 0.5 %
-// SLOWER than register staging at cfg2 level 0, profiles/r05_attn_il40_dma_ab.txt: the loop is bound by the VALU issue
-// port, not by its staging): K and V^T tiles go global -> LDS by `global_load_lds_dwordx4` instead of through
-// registers: no staging VGPRs, no ds_write pass, 10 DMA instructions per workgroup and tile instead of 32 loads + writes.
-// The DMA writes lane-linearly, so the images are dense: K rows of DH elements (the QK^T k-step that straddles DH reads
-// the next row's first elements against ZERO columns of Q; 80-B rows are bank-conflict-free as they are), V^T rows of 64
-// keys whose 16-B pieces are XOR-swizzled with (row & 7) on the DMA's source address and on the fragment read.  A tile is
-// issued right behind the barrier that frees its buffer and drained (vmcnt(0)) in front of the next one: the same
+// DMA != 0 (non-PACK forms): K and V^T tiles go global -> LDS by `global_load_lds_dwordx4` instead of through registers: no
+// staging VGPRs, no ds_write pass.  The DMA writes lane-linearly (wave-uniform LDS base + lane * 16 B per instruction, a
+// "piece" of 1 KB), the per-lane SOURCE address is free, so any LDS image whose 16-B slots are filled piece by piece works:
+//   DMA = 1 (round 5, Dh = 40; A/B switch TF_TUNE_IL40_DMA, OFF: 0.5 % slower than register staging at cfg2 level 0,
+//           profiles/r05_attn_il40_dma_ab.txt): DENSE images, K rows of DH elements (the QK^T k-step that straddles DH reads the
+//           next row's first elements against ZERO columns of Q), V^T rows of 64 keys XOR-swizzled with (row & 7) on the source
+//           address and on the fragment read -- one address computation per fragment read;
+//   DMA = 2 (round 6): the PADDED images of the register-staged form (row strides of an odd number of 16-B slots), so every
+//           fragment address stays "per-lane base + immediate".  A lane whose slot is row padding fetches slot 0 of its row
+//           (finite data: the K pad columns meet zero columns of Q, the V^T pad columns are never read); the lanes of a last,
+//           partial piece past the end of the image are masked off (the constant rows behind it must survive).
+// A tile is issued right behind the barrier that frees its buffer and drained (vmcnt(0)) in front of the next one: the same
 // distance the register staging had.
-template <typename T, int DH, int NW, int MODE, int MINW, bool DMA = false>
+template <typename T, int DH, int NW, int MODE, int MINW, int DMA = 0>
 __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p) {
     typedef AttnCfg<DH, 64> C;
     typedef typename T::elem E;
@@ -1225,9 +1287,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     static_assert(!PACK || DH == 40, "the packed dual-V image is a Dh = 40 form");
     constexpr int VR = PACK ? 2 * DH : DH;              // staged V^T rows per tile
     constexpr int MT = PACK ? 3 : C::MT;                // P.V M-tiles
-    static_assert(!DMA || (!PACK && (64 * DH * 2) % 1024 == 0 && (VR * 128) % 1024 == 0), "DMA form: whole 1 KB pieces");
-    constexpr int KROW = DMA ? DH : C::KROW;            // LDS row strides (elements): dense images in the DMA form
-    constexpr int VROW = DMA ? 64 : C::VROW;
+    static_assert(DMA != 1 || (!PACK && (64 * DH * 2) % 1024 == 0 && (VR * 128) % 1024 == 0), "dense DMA form: whole 1 KB pieces");
+    static_assert(DMA == 0 || !PACK, "the DMA forms stage one bank");
+    constexpr int KROW = DMA == 1 ? DH : C::KROW;       // LDS row strides (elements): dense images in the DMA = 1 form
+    constexpr int VROW = DMA == 1 ? 64 : C::VROW;
     constexpr int K_ELEMS = 64 * KROW;
     constexpr int V_ELEMS = MT * 32 * VROW;
     constexpr int NPK = C::npk(NT), NPV = (VR * 8 + NT - 1) / NT;
@@ -1235,7 +1298,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     constexpr bool ONES = (VR % 32) != 0;   // denominator from the MFMA (row VR of the V^T image = 1.0)
     constexpr int ONES_R = ((VR % 32) & 3) + 4 * ((VR % 32) >> 3);
     static_assert(!ONES || ((VR % 32) & 4) == 0, "the ones row must live in lane half 0");
-    constexpr bool BOUND = DH == 40;        // needs the key norms of the pre-pass
+    constexpr bool BOUND = attn_has_bound(DH);   // needs the key norms of the pre-pass
     constexpr float BOUND_T = std::is_same<E, _Float16>::value ? 14.0f : 60.0f;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1368,34 +1431,46 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
         for (int i = 0; i < NPV; ++i)
             if (tid + NT * i < VR * 8) st16(sV(buf) + v_loff[i], rv[i]);
     };
-    // DMA form: piece q of a tile pair = 1 KB of the K image (q < NKP) or of the V^T image; wave w issues q = w, w + NW, ..
-    constexpr int NKP = DMA ? 64 * DH * 2 / 1024 : 0, NVP = DMA ? VR * 128 / 1024 : 0;
-    constexpr int NSLOT = DMA ? (NKP + NVP + NW - 1) / NW : 1;
+    // DMA forms: a tile = NKP 1-KB pieces of the K image + NVP of the V^T image; wave w issues pieces w, w + NW, .. of each.
+    // Per-lane source offsets are unsigned BYTE offsets from the wave-uniform tile pointers, so that the DMA takes the
+    // SGPR-base + 32-bit-VGPR-offset form (no 64-bit address pair per lane)
+    constexpr int K_IMG = 64 * KROW * 2, V_IMG = VR * VROW * 2;   // staged bytes of one K / V^T image
+    constexpr int NKP = DMA ? (K_IMG + 1023) / 1024 : 0, NVP = DMA ? (V_IMG + 1023) / 1024 : 0;
+    constexpr int NKS = DMA ? (NKP + NW - 1) / NW : 1, NVS = DMA ? (NVP + NW - 1) / NW : 1;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    int d_goff[NSLOT];
-    if constexpr (DMA) {
+    uint32_t dk_goff[NKS], dv_goff[NVS];
+    bool dk_ok[NKS], dv_ok[NVS];   // this lane's slot lies inside the image (false only in a last, partial piece)
+    if constexpr (DMA != 0) {
 #pragma unroll
-        for (int n = 0; n < NSLOT; ++n) {
-            const int q = wave_u + NW * n;
-            if (q < NKP) {
-                const int o = q * 1024 + lane * 16;
-                const int row = o / (2 * DH);
-                d_goff[n] = row * (int)p.ld + ((o - row * 2 * DH) >> 1);
-            } else {
-                const int o = (q - NKP) * 1024 + lane * 16;
-                const int row = o >> 7, sl = (o & 127) >> 4;
-                d_goff[n] = row * (int)vt_row + ((sl ^ (row & 7)) << 3);
-            }
+        for (int n = 0; n < NKS; ++n) {
+            const int o = (wave_u + NW * n) * 1024 + lane * 16;
+            const int row = min(o / (2 * KROW), 63);
+            const int pc = (o - row * 2 * KROW) >> 4;          // 16-B slot of the LDS row this lane fills
+            dk_ok[n] = o < K_IMG;
+            dk_goff[n] = (uint32_t)(row * (int)p.ld + ((pc < DH / 8 ? pc : 0) << 3)) * 2u;
+        }
+#pragma unroll
+        for (int n = 0; n < NVS; ++n) {
+            const int o = (wave_u + NW * n) * 1024 + lane * 16;
+            const int row = min(o / (2 * VROW), VR - 1);
+            const int sl = (o - row * 2 * VROW) >> 4;
+            dv_ok[n] = o < V_IMG;
+            dv_goff[n] = (uint32_t)(row * (int)vt_row + ((DMA == 1 ? sl ^ (row & 7) : sl < 8 ? sl : 0) << 3)) * 2u;
         }
     }
     auto dma_k = [&](int buf) {      // the next K tile -> Kbuf[buf]
 #pragma unroll
-        for (int n = 0; n < NSLOT; ++n) {
+        for (int n = 0; n < NKS; ++n) {
             const int q = wave_u + NW * n;
-            if (q < NKP)
-                __builtin_amdgcn_global_load_lds((glb_ptr)(k_next + d_goff[n]), (lds_ptr)(sK(buf) + q * 512), 16, 0, 0);
+            if (NKP % NW == 0 || q < NKP) {
+                uint32_t off = dk_goff[n];
+                asm volatile("" : "+v"(off));   // keeps the zero-extension next to the add: SGPR base + 32-bit VGPR offset form
+                if (K_IMG % 1024 == 0 || dk_ok[n])
+                    __builtin_amdgcn_global_load_lds((glb_ptr)(reinterpret_cast<const char*>(k_next) + off),
+                                                     (lds_ptr)(sK(buf) + q * 512), 16, 0, 0);
+            }
         }
         const bool wrap = k_tt == tpf - 1;
         k_next += wrap ? k_wrap_off : (int64_t)64 * p.ld;
@@ -1403,10 +1478,15 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     };
     auto dma_v = [&](int buf) {      // the next V^T tile -> Vbuf[buf]
 #pragma unroll
-        for (int n = 0; n < NSLOT; ++n) {
+        for (int n = 0; n < NVS; ++n) {
             const int q = wave_u + NW * n;
-            if (q >= NKP && q < NKP + NVP)
-                __builtin_amdgcn_global_load_lds((glb_ptr)(v_next + d_goff[n]), (lds_ptr)(sV(buf) + (q - NKP) * 512), 16, 0, 0);
+            if (NVP % NW == 0 || q < NVP) {
+                uint32_t off = dv_goff[n];
+                asm volatile("" : "+v"(off));
+                if (V_IMG % 1024 == 0 || dv_ok[n])
+                    __builtin_amdgcn_global_load_lds((glb_ptr)(reinterpret_cast<const char*>(v_next) + off),
+                                                     (lds_ptr)(sV(buf) + q * 512), 16, 0, 0);
+            }
         }
         const bool wrap = v_tt == tpf - 1;
         v_next += wrap ? v_wrap : 64;
@@ -1482,7 +1562,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
         const int r = un * 2;
         const f32x2 x = f32x2{s[X][r], s[X][r + 1]} * c2 - mc2;
         const float p0 = __builtin_amdgcn_exp2f(x[0]), p1 = __builtin_amdgcn_exp2f(x[1]);
-        if constexpr (!ONES) lsum += p0 + p1;
+        if constexpr (!ONES) {
+            lsum += p0 + p1;
+#ifndef TF_TUNE_IL_LSUM_SINK
+            // the running sum must exist HERE: otherwise the 16 adds of a phase sink to its end as one dependent chain
+            // behind the last MFMA (nothing of this wave on the matrix pipe meanwhile) instead of riding in the MFMA gaps
+            asm volatile("" : "+v"(lsum));
+#endif
+        }
         pf[X][r >> 3][r & 7] = (E)p0;
         pf[X][r >> 3][(r & 7) + 1] = (E)p1;
     };
@@ -1503,12 +1590,12 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
             const float mc = m_run * c;
             mc2 = f32x2{mc, mc};
         }
-        const E* vbase = sV(vbuf) + l31 * VROW + (DMA ? 0 : Hh * 32 + 8 * hi);
+        const E* vbase = sV(vbuf) + l31 * VROW + (DMA == 1 ? 0 : Hh * 32 + 8 * hi);
         const E* kbase = sK(kbuf) + (Hh * 32 + l31) * KROW + 8 * hi;
         const int vswz = l31 & 7;   // DMA form: 16-B piece index of row (32 a + l31) is XOR-ed with row & 7
         auto frag = [&](int i) -> vec8 {
             if (sch.is_pv[i]) {
-                if constexpr (DMA)
+                if constexpr (DMA == 1)
                     return __builtin_bit_cast(vec8, ld16(vbase + sch.a[i] * 32 * VROW + (((4 * Hh + hi + 2 * sch.b[i]) ^ vswz) << 3)));
                 return __builtin_bit_cast(vec8, ld16(vbase + sch.a[i] * 32 * VROW + 16 * sch.b[i]));
             }
@@ -1553,7 +1640,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     typedef std::false_type No;
 
     // ---- prologue: K(0) -> Kbuf[0]; S(0) = K(0) Q; P0(0); registers <- K(1), V(0)
-    if constexpr (DMA) {
+    if constexpr (DMA != 0) {
         __syncthreads();        // LDS init done before the first DMA lands
         dma_k(0);               // K(0)
         dma_wait();
@@ -1587,14 +1674,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     // All tiles but the last: every phase also runs the QK^T half of the NEXT tile.  The last tile is peeled (no
     // branch on "is there a next tile" inside the loop: the two shapes of the body would otherwise make the
     // compiler keep two copies of the O accumulators and copy between them).
-    if constexpr (DMA) {
+    if constexpr (DMA != 0) {
         // Kbuf[1] and Vbuf[0] hold nothing yet: K(1), V(0) may be issued at once (every wave is past the LDS init)
         if (ntiles > 1) dma_k(1);
         dma_v(0);
     }
     for (int t = 0; t + 1 < ntiles; ++t) {
         const int cur = t & 1, nxt = cur ^ 1;
-        if constexpr (DMA) {
+        if constexpr (DMA != 0) {
             dma_wait();                   // this wave's pieces of K(t+1), V(t) have landed ...
             __syncthreads();              // ... everybody's have; every wave has left iteration t-1, whose phases were the
             __builtin_amdgcn_sched_barrier(0);   // last readers of Kbuf[cur] (K(t)) and Vbuf[nxt] (V(t-1)): free to refill
@@ -1617,7 +1704,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     }
     {
         const int cur = (ntiles - 1) & 1;
-        if constexpr (DMA) dma_wait();
+        if constexpr (DMA != 0) dma_wait();
         else write_v(cur);            // V(n-1)
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
@@ -1679,10 +1766,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     }
 }
 
-template <typename T, int DH, int NW, int MODE, int MINW, bool DMA = false>
+template <typename T, int DH, int NW, int MODE, int MINW, int DMA = 0>
 int launch_il(AttnParams p, hipStream_t st) {
     typedef AttnCfg<DH, 64> C;
-    constexpr size_t lds = DMA                 ? 2 * (size_t)(64 * DH + C::MT * 32 * 64) * 2 + 16   // dense images (+ the K over-read)
+    constexpr size_t lds = DMA == 1            ? 2 * (size_t)(64 * DH + C::MT * 32 * 64) * 2 + 16   // dense images (+ the K over-read)
                            : MODE == MODE_DUAL ? 2 * (size_t)(C::K_ELEMS + 96 * C::VROW) * 2        // packed dual-V image
                                                : C::lds_bytes(1);
     auto kern = ext_attn_il_kernel<T, DH, NW, MODE, MINW, DMA>;
@@ -1746,7 +1833,7 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
         dim3 grid((unsigned)(p.Spad / 64), (unsigned)p.H, (unsigned)((b_hi - b_lo) * p.K));
         const size_t lds = (size_t)64 * (DH + 2) * sizeof(E);
         // the Dh = 40 kernels also need the key norm bounds (score bound, see BOUND)
-        const bool bound = DH == 40;
+        const bool bound = attn_has_bound(DH);
         hipLaunchKernelGGL(vt_pack_kernel<T>, grid, dim3(256), lds, st, reinterpret_cast<const E*>(v),
                            reinterpret_cast<E*>(const_cast<void*>(p.vt)),
                            bound ? reinterpret_cast<const E*>(p.k) : nullptr, const_cast<float*>(p.knorm2),
@@ -1794,14 +1881,14 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
 #endif
 #ifdef TF_TUNE_IL40_DMA
             if (il)
-                return compose([&] { return launch_il<T, 40, 8, MODE_ALL, 4, true>(p, st); },
+                return compose([&] { return launch_il<T, 40, 8, MODE_ALL, 4, TF_TUNE_IL40_DMA>(p, st); },
                                [&] {
 #ifndef TF_TUNE_NO_IL40_DUAL
                                    if (p.S >= 256 && p.S % 64 == 0) return launch_il<T, 40, 4, MODE_DUAL, 3>(p, st);
 #endif
                                    return launch_one<T, DH, 1, 4, MODE_DUAL, 3, false>(p, st);
                                },
-                               [&] { return launch_il<T, 40, 8, MODE_SOURCE, 4, true>(p, st); });
+                               [&] { return launch_il<T, 40, 8, MODE_SOURCE, 4, TF_TUNE_IL40_DMA>(p, st); });
 #endif
             return compose([&] {
 #ifdef TF_TUNE_IL40_NW4_SMALL
@@ -1847,11 +1934,14 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
 #ifndef TF_TUNE_IL64_MINW
 #define TF_TUNE_IL64_MINW 3
 #endif
+#ifndef TF_TUNE_IL64_DMA
+#define TF_TUNE_IL64_DMA 2
+#endif
         const bool il = p.S % 64 == 0 && p.S >= 512;   // half-tile interleaved form (ext_attn_il_kernel)
         if (il)
-            return compose([&] { return launch_il<T, DH, TF_TUNE_IL64_NW, MODE_ALL, TF_TUNE_IL64_MINW>(p, st); },
+            return compose([&] { return launch_il<T, DH, TF_TUNE_IL64_NW, MODE_ALL, TF_TUNE_IL64_MINW, TF_TUNE_IL64_DMA>(p, st); },
                            [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st); },
-                           [&] { return launch_il<T, DH, TF_TUNE_IL64_NW, MODE_SOURCE, TF_TUNE_IL64_MINW>(p, st); });
+                           [&] { return launch_il<T, DH, TF_TUNE_IL64_NW, MODE_SOURCE, TF_TUNE_IL64_MINW, TF_TUNE_IL64_DMA>(p, st); });
 #endif
         return compose([&] { return (p.S >= 512 && p.nseg == 1) ? launch_pp<T, DH, MODE_ALL, 2>(p, st)   // ping-pong: +8..11 %
                                                : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st); },
@@ -1869,10 +1959,13 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
 #else
         const bool il = false;
 #endif
-        return compose([&] { return il ? launch_il<T, DH, TF_TUNE_IL80_NW, MODE_ALL, TF_TUNE_IL80_MINW>(p, st)
+#ifndef TF_TUNE_IL80_DMA
+#define TF_TUNE_IL80_DMA 0
+#endif
+        return compose([&] { return il ? launch_il<T, DH, TF_TUNE_IL80_NW, MODE_ALL, TF_TUNE_IL80_MINW, TF_TUNE_IL80_DMA>(p, st)
                                        : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st); },
                        [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st); },
-                       [&] { return il ? launch_il<T, DH, TF_TUNE_IL80_NW, MODE_SOURCE, TF_TUNE_IL80_MINW>(p, st)
+                       [&] { return il ? launch_il<T, DH, TF_TUNE_IL80_NW, MODE_SOURCE, TF_TUNE_IL80_MINW, TF_TUNE_IL80_DMA>(p, st)
                                        : launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st); });
     } else {
         // Dh=160: the dual (shared-softmax) form needs 160 more accumulator registers and measured slower;

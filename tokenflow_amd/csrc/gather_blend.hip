@@ -420,8 +420,8 @@ static int nn_gather_blend_impl(const char* name, const void* tgt, const void* p
                (P == 1 || (kf1 >= 0 && kf1 < K)),
            TF_ERR_SHAPE, "%s: K=%d n=%d S=%d D=%d P=%d kf=(%d,%d)", name, K, n, S, D, P, kf0, kf1);
     TF_ARG(tf_aligned16(tgt) && tf_aligned16(piv) && tf_aligned16(kf_out) && tf_aligned16(out) &&
-               tf_aligned16(resid) && tf_aligned16(ws),
-           TF_ERR_ALIGN, "%s: tensors not 16-byte aligned", name);
+               tf_aligned16(resid) && tf_aligned16(ws) && tf_aligned16(inv_norm),
+           TF_ERR_ALIGN, "%s: tensors not 16-byte aligned (inv_norm included)", name);
     if (nm.out) {
         TF_ARG((!nm.gamma && !nm.beta) || okdt(nm.w_dtype), TF_ERR_DTYPE, "%s: norm weight dtype %d", name, nm.w_dtype);
         TF_ARG(gbn_supported(D, P, in_dtype, res_dtype, out_dtype, nm.dtype, resid != nullptr), TF_ERR_DTYPE,
@@ -497,8 +497,8 @@ static int nn_gather_blend_chunks_impl(const char* name, const void* tgt, const 
            TF_ERR_SHAPE, "%s: K=%d n=%d C=%d S=%d D=%d slot0=%d first_single=%d", name, K, n, C, S, D, slot0,
            first_single);
     TF_ARG(tf_aligned16(tgt) && tf_aligned16(piv) && tf_aligned16(kf_out) && tf_aligned16(out) &&
-               tf_aligned16(resid) && tf_aligned16(ws),
-           TF_ERR_ALIGN, "%s: tensors not 16-byte aligned", name);
+               tf_aligned16(resid) && tf_aligned16(ws) && tf_aligned16(inv_norm),
+           TF_ERR_ALIGN, "%s: tensors not 16-byte aligned (inv_norm included)", name);
     if (nm.out) {
         TF_ARG((!nm.gamma && !nm.beta) || okdt(nm.w_dtype), TF_ERR_DTYPE, "%s: norm weight dtype %d", name, nm.w_dtype);
         TF_ARG(gbn_supported(D, 2, in_dtype, res_dtype, out_dtype, nm.dtype, resid != nullptr), TF_ERR_DTYPE,

@@ -966,8 +966,8 @@ extern "C" int tf_nn_search(const void* tgt, const void* piv, const float* inv_n
     TF_ARG(dtype == TF_BF16 || dtype == TF_F16, TF_ERR_DTYPE, "tf_nn_search: dtype %d (bf16/f16 only)", dtype);
     TF_ARG(n_tgt > 0 && S > 0 && D > 0 && D % 8 == 0 && (P == 1 || P == 2) && kf0 >= 0 && (P == 1 || kf1 >= 0),
            TF_ERR_SHAPE, "tf_nn_search: n_tgt=%lld S=%d D=%d P=%d kf=(%d,%d)", (long long)n_tgt, S, D, P, kf0, kf1);
-    TF_ARG(tf_aligned16(tgt) && tf_aligned16(piv) && tf_aligned16(ws), TF_ERR_ALIGN,
-           "tf_nn_search: inputs not 16-byte aligned");
+    TF_ARG(tf_aligned16(tgt) && tf_aligned16(piv) && tf_aligned16(ws) && tf_aligned16(inv_norm), TF_ERR_ALIGN,
+           "tf_nn_search: inputs not 16-byte aligned (inv_norm included: the LDS-DMA kernel fetches it in 16-byte pieces)");
     TF_ARG(ws_bytes >= tf_nn_search_workspace_bytes(n_tgt, S, D, P), TF_ERR_WORKSPACE,
            "tf_nn_search: workspace %zu < %zu bytes", ws_bytes, tf_nn_search_workspace_bytes(n_tgt, S, D, P));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

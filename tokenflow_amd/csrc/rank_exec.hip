@@ -11,8 +11,8 @@
 // communicator, one stream: no reliance on cross-stream ordering inside RCCL; a hand-over between two streams on the
 // critical path also costs ~10 us of idle device each way, profiles/r04_rank_timeline_v1.txt).  Two side streams:
 // an auxiliary COMPUTE stream runs the source branch of the local frames beside the first exchange and the bank
-// attention where those are separate launches (level 0; forked and joined by events, nothing waits on it before the
-// join), and the neighbour halo has a stream of its own (with its own communicator when the host gives one:
+// attention where those are separate launches (level 0; forked behind the pack -- in FRONT of the exchange -- and joined
+// in front of the second exchange by events, nothing waits on it before the join), and the neighbour halo has a stream of its own (with its own communicator when the host gives one:
 // collectives of ONE RCCL communicator execute in issue order, and a 10 MB halo message in front of the next block's
 // all-to-all would sit on the critical path); it has the rest of the pass to arrive.  All ordering is by events; no
 // host synchronisation anywhere.
@@ -282,37 +282,39 @@ extern "C" int tf_rank_pivotal(tf_rank* rk, const void* q, const void* k, const 
         // Everything on the caller's stream, collectives included: every collective of the communicator is issued on
         // ONE stream (no reliance on RCCL's ordering of one communicator across streams), and a hand-over between two
         // streams costs ~10 us of idle device each way (profiles/r04_rank_timeline_v1.txt: four of them per block were
-        // 45 us of a 120 us block at the coarse levels).  Up to round 4 the level-0 form kept the first exchange on a
-        // side stream so that the source branch ran under the wire; that is ~40 us of wire per level-0 block left
-        // exposed now (estimated: no multi-GPU node to measure it), against two cross-stream dependencies removed.
+        // 45 us of a 120 us block at the coarse levels).
+        // Where the source branch of the local frames is a launch of its own (level 0: the fused plan does not apply), it
+        // runs on the auxiliary COMPUTE stream, forked HERE -- behind the pack, in front of the first exchange: it reads
+        // only the caller's q / k / v, so it runs under the exchange's wire time and then beside the bank launch, which
+        // absorbs what is left of it (a rank's own frames are too few workgroups to fill the chip: cfg2 level 0 at W = 8,
+        // 128 workgroups, 61 us alone; 471 -> 440 us per level-0 block with the wire taken out,
+        // profiles/r05_rank_step_srcaux_ab.txt).  Joined in front of the second exchange.  The collectives stay on the
+        // caller's stream.  TOKENFLOW_RANK_SRC_AUX=0: in line on the caller's stream, behind the exchange.
+        static const bool src_aux = [] { const char* e = getenv("TOKENFLOW_RANK_SRC_AUX"); return !e || atoi(e) != 0; }();
+        const int64_t src_strides[9] = {q_bs, q_fs, k_bs, k_fs, v_bs, v_fs, o_bs, SD, ld_q};
+        auto source_branch = [&](hipStream_t on) {
+            return tf_ext_attn_fwd_strided(q, k, v, out_loc, Kl, Kl, 0, S, H, Dh, ld, src_strides, scale,
+                                           flags | TF_ATTN_SOURCE_ONLY, dtype, wsb + L.ws_src, L.ws_src_bytes, on);
+        };
+        const bool fork = !plan.use && src_aux;
+        if (fork) {
+            if (const int rc = order(rk, st, rk->as, "tf_rank_pivotal")) return rc;
+            if (const int rc = source_branch(rk->as)) return rc;
+        }
         if (const int rc = tf_all_to_all_rows(rk->comm, send, recv, own, cnt, ns * Shd, dtype, st)) return rc;
         if (plan.use) {
             // small problems (the coarse levels, a rank's share of the middle ones): ONE launch for both sets behind
             // the exchange -- no V^T pre-passes, no split + merge pair, no separate source launch
             if (const int rc = tf_attn_fused_launch(sets, 2, S, Dh, scale, flags, dtype, plan, st)) return rc;
         } else {
-            // The source branch of the local frames (independent of the exchange) on the auxiliary COMPUTE stream, beside
-            // the exchange and the bank launch: a rank's own frames are too few workgroups to fill the chip (cfg2 level 0
-            // at W = 8: 128 workgroups, 61 us alone); beside the bank launch they are absorbed -- 471 -> 440 us per level-0
-            // block, 4.26 -> 4.08 ms per rank step with the wire taken out (profiles/r05_rank_step_srcaux_ab.txt) -- and on
-            // a real wire they run under the first exchange.  Collectives stay on the caller's stream.
-            // TOKENFLOW_RANK_SRC_AUX=0: in line on the caller's stream.
-            static const bool src_aux = [] { const char* e = getenv("TOKENFLOW_RANK_SRC_AUX"); return !e || atoi(e) != 0; }();
-            {
-                if (src_aux)
-                    if (const int rc = order(rk, st, rk->as, "tf_rank_pivotal")) return rc;
-                const int64_t strides[9] = {q_bs, q_fs, k_bs, k_fs, v_bs, v_fs, o_bs, SD, ld_q};
-                if (const int rc = tf_ext_attn_fwd_strided(q, k, v, out_loc, Kl, Kl, 0, S, H, Dh, ld, strides, scale,
-                                                           flags | TF_ATTN_SOURCE_ONLY, dtype,
-                                                           wsb + L.ws_src, L.ws_src_bytes, src_aux ? rk->as : st))
-                    return rc;
-            }
+            if (!fork)
+                if (const int rc = source_branch(st)) return rc;
             const int64_t strides[9] = {Shd, fs_r, Shd, fs_r, Shd, fs_r, Shd, 2 * Shd, hd};
             if (const int rc = tf_ext_attn_fwd_strided(qb, kb, vb, ob, K, K, 0, S, Hl, Dh, hd, strides, scale,
                                                        flags | TF_ATTN_BANK_ONLY, dtype,
                                                        wsb + L.ws_bank, L.ws_bank_bytes, stream))
                 return rc;
-            if (src_aux)
+            if (fork)
                 if (const int rc = order(rk, rk->as, st, "tf_rank_pivotal")) return rc;
         }
         // ---- outputs back to the frame owners: on the caller's stream (nothing can run beside this exchange: the

@@ -93,7 +93,9 @@ def register_frame_shard(diffusion_model, shard):
         rank's halo-extended caches, the first one waiting for the neighbour's message.
     Results equal the single-process hooks' in the bit-stable mode (TOKENFLOW_ATTN_NO_SPLIT=1) bit for bit (`FrameShard`'s
     default one-pass attention; against the default single-process mode: within the attention's parity bound); every rank must
-    draw the same `pivotal_idx` (run_tokenflow_pnp.py:224).  INTEGRATION.md section 3 shows the driver side."""
+    draw the same `pivotal_idx` (run_tokenflow_pnp.py:224).  INTEGRATION.md section 3 shows the driver side.
+    A world-1 shard (one GPU) runs the bit-stable attention mode too unless it was built with `attn_split=True`: slower
+    than the plain single-process hooks by the per-grid kernel choice it gives up (`tools/hooks_bench.py --ranks 1`)."""
     for module in _tokenflow_blocks(diffusion_model):
         module.__dict__["_tf_shard"] = shard
         module.__dict__.pop("_tf_halo", None)

@@ -45,7 +45,17 @@ def _launch(dev, what: str, fn, *args, stream: Optional[int] = None):
 # projections already arrive in the autocast dtype).  bf16 (default) cannot overflow; TOKENFLOW_FP32_AS=f16 keeps 11
 # significand bits instead of 8 -- the reference's own GPU dtype (run_tokenflow_pnp.py:47, 220) -- for models whose
 # activations stay inside f16's range.
-FP32_AS = {"bf16": torch.bfloat16, "f16": torch.float16}[os.environ.get("TOKENFLOW_FP32_AS", "bf16")]
+def _fp32_as_from_env() -> torch.dtype:
+    name = os.environ.get("TOKENFLOW_FP32_AS", "bf16").strip().lower()
+    table = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f16": torch.float16, "fp16": torch.float16,
+             "float16": torch.float16, "half": torch.float16}
+    if name not in table:
+        raise ValueError(f"TOKENFLOW_FP32_AS={name!r}: must be 'bf16' or 'f16' (aliases: bfloat16, fp16, float16, half)")
+    return table[name]
+
+
+# f16 has no overflow guard: an fp32 activation above 65504 becomes inf in q / k / v / the pivots
+FP32_AS = _fp32_as_from_env()
 
 
 def compute_dtype(t: torch.Tensor) -> torch.dtype:

@@ -127,6 +127,9 @@ class FrameShard:
         # on a rank's attention at 8 GPUs; results then agree with the single-GPU ones within the
         # output rounding).  Default False: one pass per bank problem, arithmetic independent of the grid, sharded
         # results equal to single-GPU results bit for bit.  None reads TOKENFLOW_SHARD_ATTN_SPLIT.
+        # A WORLD-1 shard follows the same rule (it equals a world-W shard bit for bit), which means it runs the
+        # bit-stable mode and loses the single-GPU default's per-grid kernel choice (+26 % at cfg2 level 2): pass
+        # attn_split=True when a world-1 shard is registered for speed, not for bit stability.
         if attn_split is None:
             attn_split = os.environ.get("TOKENFLOW_SHARD_ATTN_SPLIT", "0") not in ("", "0")
         self.attn_split = bool(attn_split)
@@ -304,7 +307,10 @@ class FrameShard:
         out4: a [3,Kl,S,D] view (dense frames, free branch stride) the result is written into in place -- the
         keyframe slots 1.. of a halo-extended buffer (`ext_alloc`); returned as is."""
         if self.world == 1:
-            # the same mode as a rank of a larger world: a world-1 shard equals a world-W shard bit for bit by default
+            # the same mode as a rank of a larger world: a world-1 shard equals a world-W shard bit for bit by default.
+            # COST: with attn_split unset this is the bit-stable mode (no_split), which gives up the single-GPU default's
+            # per-grid kernel choice (cfg2 level 2: 124 against 98 us per block, profiles/r05_attn_nosplit_ab.txt).  A
+            # single-GPU user who registers a world-1 shard for speed passes attn_split=True.
             ns = not self.attn_split
             if out4 is None:
                 return ops.ext_attn(q_local, k_local, v_local, heads, scale, inject, no_split=ns)

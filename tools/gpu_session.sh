@@ -20,6 +20,20 @@ for stage in "$@"; do
                   rm -rf /tmp/p40; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/p40 -- python $GRAFT_REPO_ROOT/tools/attn_microbench.py 8,4096,8,40 > /dev/null 2>>$GRAFT_REPO_ROOT/$O/pmc40.err )
                   DB=$(find /tmp/p40 -name "*_results.db" | head -1); [ -n "$DB" ] && python tools/rocpd_pmc.py $DB | grep "il_kernel<BF16; 40; 8; 0\|^kernel" >> $O/pmc_l0_accounting.csv; done
                 cut -c1-60,100-220 $O/pmc_l0_accounting.csv ;;
+    r6ab)       # round 6: d = 64 / 40 / 80 streaming attention variants (tools/build_variants.sh), one process per library
+                for lib in base "" il64a il64b il64c il64e base "" il64a; do echo "== lib=${lib:-default}" | tee -a $O/attn_d64_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 10,9216,5,64 25,4096,5,64 10,2304,10,64 25,1024,10,64 2>/dev/null | grep "inject=0" | tee -a $O/attn_d64_ab.txt; done
+                for lib in "" il40p "" il40p; do echo "== lib=${lib:-default}" | tee -a $O/attn_d40_dma2_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 8,4096,8,40 4,1024,8,40 2>/dev/null | grep "inject=0" | tee -a $O/attn_d40_dma2_ab.txt; done
+                for lib in "" il80a il80b "" il80a il80b; do echo "== lib=${lib:-default}" | tee -a $O/attn_d80_dma2_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 8,1024,8,80 4,256,8,80 2>/dev/null | grep "inject=0" | tee -a $O/attn_d80_dma2_ab.txt; done ;;
+    r6abtests)  for lib in ${R6_TEST_LIBS:-"" il64a}; do echo "== lib=${lib:-default}" | tee -a $O/attn_variant_tests.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_baseline_configs_gpu.py tests/test_fullsize_gpu.py -q --tb=line -p no:cacheprovider -k "attn or cfg4 or cfg5 or cfg2" 2>&1 | tail -6 | tee -a $O/attn_variant_tests.txt; done ;;
+    pmc64)      # instruction-level accounting of the d = 64 level-0 kernel at cfg4; PMC64_LIB selects the build
+                for grp in "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES" "SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_THREAD_CYCLES_VALU" "SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32" "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_IFETCH" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VALU_INT32" "SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VALU2 SQ_BUSY_CU_CYCLES SQ_WAVES"; do
+                  rm -rf /tmp/p64; ( cd /tmp && TOKENFLOW_HIP_LIB=${PMC64_LIB:+$GRAFT_REPO_ROOT/build/variants/lib_$PMC64_LIB.so} timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/p64 -- python $GRAFT_REPO_ROOT/tools/attn_microbench.py 10,9216,5,64 > /dev/null 2>>$GRAFT_REPO_ROOT/$O/pmc64.err )
+                  DB=$(find /tmp/p64 -name "*_results.db" | head -1); [ -n "$DB" ] && python tools/rocpd_pmc.py $DB | grep "pp_kernel<BF16; 64; 0\|il_kernel<BF16; 64; [48]; 0\|^kernel" >> $O/pmc_d64_${PMC64_LIB:-default}.csv; done
+                cut -c1-60,100-220 $O/pmc_d64_${PMC64_LIB:-default}.csv ;;
     seam2)      timeout 900 python -m pytest tests/test_driver_seam.py tests/test_sharded_gpu.py -m gpu -q --tb=short -p no:cacheprovider -s -k "driver or shard_vs_default" 2>&1 | grep -v "^$" | tail -60 > $O/seam2_tests.txt; grep -ai "driver seam\|passed\|failed\|Error\|assert" $O/seam2_tests.txt | cut -c1-300 ;;
     inputsab)   for n in 1 0 1 0; do timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-yardstick --no-parity --input-sets $n > $O/bench_sets_$n.json 2>> $O/inputsab.err; python -c "import json;d=json.load(open('$O/bench_sets_$n.json'));print('input sets',d['input_sets']['n'],d['ms_per_step'],d['ms_per_step_inject_on'],d['ms_per_step_inject_off'],d['roofline']['avg_launch_ms'])" | tee -a $O/input_sets_ab.txt; done ;;
     src4ab)     for lib in "" nosrc4 "" nosrc4; do echo "== lib=${lib:-current}" | tee -a $O/rank_step_src4_ab.txt

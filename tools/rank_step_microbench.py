@@ -127,6 +127,11 @@ def main():
     ap.add_argument("--no-copies", action="store_true",
                     help="--native: the loopback exchanges move nothing (tf_comm_loopback_copies(0)): the rank step with the "
                          "stand-in copies excluded from the GPU time as well")
+    ap.add_argument("--wire-model", default="", metavar="LAT_US,GBPS",
+                    help="--native: the loopback transport's wire MODEL (tf_comm_loopback_wire): every exchange also holds "
+                         "its stream for LAT_US + bytes on its busiest link / GBPS GB/s (e.g. 25,50), so the overlap of the "
+                         "exchanges with compute is executed; prints the step under the model and the exchange time it "
+                         "leaves exposed (against the same step with the wire switched off)")
     ap.add_argument("--native", action="store_true",
                     help="sharded.NativeShard: the pivotal pass of a block as ONE library call (tf_rank_pivotal) on the "
                          "library's loopback transport (tf_comm_init_loopback: the same wire-less stand-in, in C)")
@@ -139,12 +144,14 @@ def main():
         for mode in (None, "heads", "bank"):
             if args.only and args.only != f"{'split' if split else 'onepass'},{mode or 'auto'}":
                 continue
+            wire = tuple(float(x) for x in args.wire_model.split(",")) if args.wire_model else None
             if args.native:
+                from tokenflow_amd import _lib
                 from tokenflow_amd.comm import HipComm
-                comm = HipComm.loopback(args.rank, args.world, copies=not args.no_copies)
+                comm = HipComm.loopback(args.rank, args.world, copies=not args.no_copies, wire=wire)
                 comm.bytes = 0
-                shard = sharded.NativeShard(cfg.K, comm, HipComm.loopback(args.rank, args.world, copies=not args.no_copies),
-                                            attn_split=split)
+                hcomm = HipComm.loopback(args.rank, args.world, copies=not args.no_copies, wire=wire)
+                shard = sharded.NativeShard(cfg.K, comm, hcomm, attn_split=split)
             else:
                 comm = LocalComm(args.rank, args.world)
                 shard = sharded.FrameShard(cfg.K, comm=comm, attn_split=split)
@@ -172,9 +179,19 @@ def main():
             for inj in (False, True):
                 gpu, host = measure(lambda: bench.run_step(cfg, blocks, shard, inj, w, exchange=mode), args.reps, 3)
                 med = statistics.median(gpu)
+                tag = f"wire model {wire[0]:g} us + bytes / {wire[1]:g} GB/s per link" if wire else "wire-less"
                 print(f"  step inject={int(inj)}: GPU {fmt(gpu)} us   host issue {fmt(host)} us   -> "
-                      f"{args.single_ms * 1e3 / med:4.2f}x of the {args.single_ms} ms single-GPU step (wire-less)",
+                      f"{args.single_ms * 1e3 / med:4.2f}x of the {args.single_ms} ms single-GPU step ({tag})",
                       flush=True)
+                if wire and args.native:   # the same step, wire off: the difference is the exchange time left exposed
+                    for c in (comm, hcomm):
+                        _lib.check(_lib.load().tf_comm_loopback_wire(c._h, 0.0, 0.0), "tf_comm_loopback_wire")
+                    gpu0, _ = measure(lambda: bench.run_step(cfg, blocks, shard, inj, w, exchange=mode), args.reps, 3)
+                    for c in (comm, hcomm):
+                        _lib.check(_lib.load().tf_comm_loopback_wire(c._h, wire[0], wire[1]), "tf_comm_loopback_wire")
+                    med0 = statistics.median(gpu0)
+                    print(f"    wire off: GPU {fmt(gpu0)} us -> exposed exchange time {med - med0:7.1f} us per step "
+                          f"({(med - med0) / 16:5.1f} us per block)", flush=True)
             comm.bytes = 0
             bench.run_step(cfg, blocks, shard, False, w, exchange=mode)
             torch.cuda.synchronize()
