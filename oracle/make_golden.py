@@ -183,6 +183,8 @@ def gen_blocks(tfu):
                 tfu.register_batch_idx(pipe, c)
                 run["chunks"].append([digest(blk(x, encoder_hidden_states=inp["enc_n"]), 61)
                                       for blk, x in zip(blocks, inp["chunks"][c])])
+                # the state a propagation pass leaves behind (tokenflow_utils.py:361-363): the selected keyframe outputs
+                run.setdefault("chunk_attn_state", []).append([digest(blk.attn_output, 61) for blk in blocks])
             run["resnet"] = digest(pipe.unet.up_blocks[1].resnets[1](inp["res_x"], inp["res_temb"]), 3)
         out["runs"][t] = run
     return out

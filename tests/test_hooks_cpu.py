@@ -64,6 +64,10 @@ def test_blocks_match_reference_golden(fake_ops, golden_blocks):
                 tfu.register_batch_idx(pipe, c)
                 for i, (blk, x) in enumerate(zip(blocks, inp["chunks"][c])):
                     check(blk(x, encoder_hidden_states=inp["enc_n"]), run["chunks"][c][i], 3e-5, f"t{t}/chunk{c}/{i}")
+                    # the state attribute the reference leaves after a propagation pass (361-363): the selected
+                    # keyframe outputs [3, len(batch_idxs), S, D] in the order [i, i-1]
+                    check(blk.attn_output, run["chunk_attn_state"][c][i], 3e-5, f"t{t}/chunk{c}/{i}/attn_output")
+                    assert blk.attn_output.shape[1] == (1 if c == 0 else 2)
             y = pipe.unet.up_blocks[1].resnets[1](inp["res_x"], inp["res_temb"])
             check(y, run["resnet"], 1e-6, f"t{t}/resnet")
         # injection fires on exactly the 8 decoder blocks and only for scheduled timesteps (206-214)

@@ -775,6 +775,34 @@ static int split_plan(int K, int Kq, int S, int H, int Dh, bool inject, int part
     if (K * tpf < 16) return 1;   // a bank of a few tiles: the merge launch costs more than it buys (8x8 level)
     int nseg = 1;
     while (wgs * 4 * nseg < (int64_t)occ * 1024 && nseg * 2 <= K && (K / (nseg * 2)) * tpf >= 2) nseg *= 2;
+    // TOKENFLOW_ATTN_NSEG=n (experiments): force n runs
+    static const int forced = [] { const char* e = getenv("TOKENFLOW_ATTN_NSEG"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return forced <= K ? forced : K;
+#ifndef TF_TUNE_NO_TAIL_SPLIT
+    // Large grids (round 6): the bank workgroups all take the same time and run in rounds of `slots` resident workgroups;
+    // a grid of 7.03 rounds (cfg4 level 0: 3600 workgroups on 512 slots) costs 8.  Splitting every bank problem into n runs of
+    // frames makes the rounds n times shorter at the price of the partial results' round trip through HBM and the merge
+    // launch: n is chosen by that model (interleaved kernels, no injection; measured in profiles/r06_attn_tail_split.txt).
+    if (nseg == 1 && !inject && S % 64 == 0 && (Dh == 64 ? S >= 512 : Dh == 40 || Dh == 80 ? S >= 256 : false)) {
+        const int qpw = Dh == 80 ? 128 : 256;                  // queries per workgroup
+        const int64_t slots = 256 * (Dh == 80 ? 3 : 2);        // resident workgroups
+        const int64_t nbank = (int64_t)2 * Kq * ((S + qpw - 1) / qpw) * H;
+        const double t_tile = 1.9;                             // us per 64-key tile of a workgroup at 4 (3) waves per SIMD
+        auto cost = [&](int n) {
+            const double rounds = (double)((nbank * n + slots - 1) / slots);
+            const double run = (double)((K + n - 1) / n) * tpf * t_tile;
+            const double merge = n > 1 ? 10.0 + 2.0 * (2.0 * Kq * H * (double)S * n * (Dh + 8) * 4.0) / 4.0e6 : 0.0;
+            return rounds * run + merge;
+        };
+        if (nbank > slots) {
+            int best = 1;
+            double best_c = cost(1) * 0.97;                    // a split must pay at least 3 %
+            for (int n = 2; n <= K && n <= 16; ++n)
+                if (((K + n - 1) / n) * tpf >= 8 && cost(n) < best_c) best = n, best_c = cost(n);
+            nseg = best;
+        }
+    }
+#endif
     // TOKENFLOW_SPLIT_OVER=n (experiments): n further doublings once the chip is full -- shorter workgroups, so that a
     // launch running BESIDE this one (a rank's source branch on an auxiliary stream) is absorbed instead of appended
     static const int over = [] { const char* e = getenv("TOKENFLOW_SPLIT_OVER"); return e ? atoi(e) : 0; }();
@@ -840,7 +868,9 @@ __global__ __launch_bounds__(256, MINW) void ext_attn_pp_kernel(AttnParams p) {
     constexpr bool FOLD = FQ && ONES && (C::DKP > DH);
     constexpr int SH_T = DH / 16, SH_HI = (DH % 16) / 8;
     constexpr float FOLD_T = 8.0f;
-    constexpr bool BOUND = attn_has_bound(DH);
+    // no score bound here: the two query tiles per wave leave no registers for it (250 VGPRs; with the bound 256 and spills
+    // inside the loop: 898 against 971 TF/s at cfg4 level 0, profiles/r06_attn_d64_ab.txt)
+    constexpr bool BOUND = false;
     constexpr float BOUND_T = std::is_same<E, _Float16>::value ? 14.0f : 60.0f;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1879,7 +1909,14 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
 #else
             const bool il = false;
 #endif
-#ifdef TF_TUNE_IL40_DMA
+            // Round 6: K / V^T tiles by LDS-DMA into the padded images (117 instead of 128 VGPRs, no ds_write pass, fragment
+            // addresses unchanged): 3.57 against 3.64 ms at cfg2 level 0 (profiles/r06_attn_d40_ab.txt; round 5's dense swizzled
+            // DMA images, TF_TUNE_IL40_DMA=1, cost an address computation per fragment read and measured -0.5 %).
+            // TF_TUNE_IL40_DMA=0: register staging.
+#ifndef TF_TUNE_IL40_DMA
+#define TF_TUNE_IL40_DMA 2
+#endif
+#if TF_TUNE_IL40_DMA != 0
             if (il)
                 return compose([&] { return launch_il<T, 40, 8, MODE_ALL, 4, TF_TUNE_IL40_DMA>(p, st); },
                                [&] {
@@ -1927,40 +1964,47 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
                        [&] { return big ? launch_one<T, DH, 1, 8, MODE_SOURCE, 2>(p, st)
                                         : launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st); });
     } else if constexpr (DH == 64) {
-#ifdef TF_TUNE_IL64
+        // Round 6: the half-tile interleaved kernel with its K / V^T tiles staged by LDS-DMA into the padded images (no staging
+        // registers: 124 VGPRs, FOUR waves per SIMD) and the score bound -- 1067 / 1082 TF/s at cfg4 / cfg5 level 0 against
+        // 971 / 982 of the ping-pong kernel on the same box (profiles/r06_attn_d64_ab.txt; the register-staged interleaved form
+        // of round 5 needed 136 VGPRs = 3 waves per SIMD and lost to it).  TF_TUNE_NO_IL64: the round-5 dispatch.
 #ifndef TF_TUNE_IL64_NW
 #define TF_TUNE_IL64_NW 8
 #endif
 #ifndef TF_TUNE_IL64_MINW
-#define TF_TUNE_IL64_MINW 3
+#define TF_TUNE_IL64_MINW 4
 #endif
 #ifndef TF_TUNE_IL64_DMA
 #define TF_TUNE_IL64_DMA 2
 #endif
-        const bool il = p.S % 64 == 0 && p.S >= 512;   // half-tile interleaved form (ext_attn_il_kernel)
-        if (il)
-            return compose([&] { return launch_il<T, DH, TF_TUNE_IL64_NW, MODE_ALL, TF_TUNE_IL64_MINW, TF_TUNE_IL64_DMA>(p, st); },
-                           [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st); },
-                           [&] { return launch_il<T, DH, TF_TUNE_IL64_NW, MODE_SOURCE, TF_TUNE_IL64_MINW, TF_TUNE_IL64_DMA>(p, st); });
+#ifndef TF_TUNE_NO_IL64
+        const bool il = p.S % 64 == 0 && p.S >= 512;
+#else
+        const bool il = false;
 #endif
-        return compose([&] { return (p.S >= 512 && p.nseg == 1) ? launch_pp<T, DH, MODE_ALL, 2>(p, st)   // ping-pong: +8..11 %
-                                               : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st); },
+        return compose([&] { return il ? launch_il<T, DH, TF_TUNE_IL64_NW, MODE_ALL, TF_TUNE_IL64_MINW, TF_TUNE_IL64_DMA>(p, st)
+                                  : (p.S >= 512 && p.nseg == 1) ? launch_pp<T, DH, MODE_ALL, 2>(p, st)   // ragged frames: ping-pong
+                                                                : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st); },
                        [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st); },
-                       [&] { return launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st); });
+                       [&] { return il ? launch_il<T, DH, TF_TUNE_IL64_NW, MODE_SOURCE, TF_TUNE_IL64_MINW, TF_TUNE_IL64_DMA>(p, st)
+                                       : launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st); });
     } else if constexpr (DH == 80) {
+        // Round 6: LDS-DMA staging (padded images) frees the staging registers: 146 VGPRs with 4-wave workgroups, THREE of which
+        // fit a CU (3 waves per SIMD, 3 x 50 KB of LDS) -- 0.442 against 0.482 ms at cfg2 level 1 (profiles/r06_attn_d80_ab.txt;
+        // register-staged: 8 waves, 166 VGPRs, 2 waves per SIMD; DMA with 8-wave workgroups: no change, 0.479)
 #ifndef TF_TUNE_IL80_NW
-#define TF_TUNE_IL80_NW 8      // 8 waves share a staged tile (165 VGPRs, 2 waves per SIMD); 4: 180 VGPRs, +1..4 %
+#define TF_TUNE_IL80_NW 4
 #endif
 #ifndef TF_TUNE_IL80_MINW
-#define TF_TUNE_IL80_MINW 2
+#define TF_TUNE_IL80_MINW 3
+#endif
+#ifndef TF_TUNE_IL80_DMA
+#define TF_TUNE_IL80_DMA 2
 #endif
 #ifndef TF_TUNE_NO_IL80
         const bool il = p.S % 64 == 0 && p.S >= 256;   // half-tile interleaved form (ext_attn_il_kernel)
 #else
         const bool il = false;
-#endif
-#ifndef TF_TUNE_IL80_DMA
-#define TF_TUNE_IL80_DMA 0
 #endif
         return compose([&] { return il ? launch_il<T, DH, TF_TUNE_IL80_NW, MODE_ALL, TF_TUNE_IL80_MINW, TF_TUNE_IL80_DMA>(p, st)
                                        : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st); },

@@ -479,6 +479,24 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
         def pivot_hidden_states(self, value):
             self.__dict__["_tf_pivot_hidden"] = (value, value.dtype)
 
+        @property
+        def attn_output(self):
+            """What the reference leaves in `self.attn_output`: the attention output after a pivotal pass (355-360), the
+            SELECTED keyframe outputs `kf_attn_output.view(3, K, S, D)[:, batch_idxs]` after a propagation pass (361-363;
+            gated under AdaLayerNormZero, 364-365).  Nothing on the path reads the second form -- the gather indexes the
+            cached output in place -- so it is built only if somebody asks."""
+            st = self.__dict__.get("_tf_attn_output")
+            if st is None:
+                raise AttributeError("attn_output: no pass has run")
+            if callable(st):
+                st = st()
+                self.__dict__["_tf_attn_output"] = st
+            return st
+
+        @attn_output.setter
+        def attn_output(self, value):
+            self.__dict__["_tf_attn_output"] = value
+
         def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None,
                     encoder_attention_mask=None, timestep=None, cross_attention_kwargs=None,
                     class_labels=None) -> torch.Tensor:
@@ -598,10 +616,16 @@ def make_tokenflow_attention_block(block_class: Type[torch.nn.Module]) -> Type[t
                     lo = s0 - 1 if c0 > 0 else s0
                     sel = kf.view(3, K, sequence_length, dim)[:, lo:s0 + n_chunks]
                     kf = (gate_msa.unsqueeze(1) * sel).reshape(-1, sequence_length, dim)
-                    self.attn_output = kf.view(3, -1, sequence_length, dim)
+                    # the attribute in the reference's order [i, i-1] (the gather source keeps ascending keyframes)
+                    self.attn_output = lambda g_=kf: g_.view(3, -1, sequence_length, dim).flip(1)
                     kf_base, K = lo, kf.shape[0] // 3
                 else:
                     kf_base = 0
+                    # 361-363: the reference leaves the selected keyframe outputs, order [i, i-1] (a run of chunks: its
+                    # keyframes in descending order); lazily -- the gather below reads the cache in place
+                    slots = list(range(s0 + n_chunks - 1, (s0 - 1 if c0 > 0 else s0) - 1, -1))
+                    self.attn_output = (lambda kf_=kf, K_=K, sl=slots:
+                                        kf_.view(3, K_, sequence_length, dim)[:, sl])
                 # 329-348: nearest neighbours of the SOURCE branch among keyframe c (and c-1), per chunk
                 tgt = norm_hidden_states[0].reshape(n_frames * sequence_length, dim).to(self._tf_pivots.dtype)
                 # 361-397: gather (same indices for the 3 branches), blend, residual -- fused with the search.
