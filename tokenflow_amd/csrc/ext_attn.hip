@@ -778,31 +778,11 @@ static int split_plan(int K, int Kq, int S, int H, int Dh, bool inject, int part
     // TOKENFLOW_ATTN_NSEG=n (experiments): force n runs
     static const int forced = [] { const char* e = getenv("TOKENFLOW_ATTN_NSEG"); return e ? atoi(e) : 0; }();
     if (forced > 0) return forced <= K ? forced : K;
-#ifndef TF_TUNE_NO_TAIL_SPLIT
-    // Large grids (round 6): the bank workgroups all take the same time and run in rounds of `slots` resident workgroups;
-    // a grid of 7.03 rounds (cfg4 level 0: 3600 workgroups on 512 slots) costs 8.  Splitting every bank problem into n runs of
-    // frames makes the rounds n times shorter at the price of the partial results' round trip through HBM and the merge
-    // launch: n is chosen by that model (interleaved kernels, no injection; measured in profiles/r06_attn_tail_split.txt).
-    if (nseg == 1 && !inject && S % 64 == 0 && (Dh == 64 ? S >= 512 : Dh == 40 || Dh == 80 ? S >= 256 : false)) {
-        const int qpw = Dh == 80 ? 128 : 256;                  // queries per workgroup
-        const int64_t slots = 256 * (Dh == 80 ? 3 : 2);        // resident workgroups
-        const int64_t nbank = (int64_t)2 * Kq * ((S + qpw - 1) / qpw) * H;
-        const double t_tile = 1.9;                             // us per 64-key tile of a workgroup at 4 (3) waves per SIMD
-        auto cost = [&](int n) {
-            const double rounds = (double)((nbank * n + slots - 1) / slots);
-            const double run = (double)((K + n - 1) / n) * tpf * t_tile;
-            const double merge = n > 1 ? 10.0 + 2.0 * (2.0 * Kq * H * (double)S * n * (Dh + 8) * 4.0) / 4.0e6 : 0.0;
-            return rounds * run + merge;
-        };
-        if (nbank > slots) {
-            int best = 1;
-            double best_c = cost(1) * 0.97;                    // a split must pay at least 3 %
-            for (int n = 2; n <= K && n <= 16; ++n)
-                if (((K + n - 1) / n) * tpf >= 8 && cost(n) < best_c) best = n, best_c = cost(n);
-            nseg = best;
-        }
-    }
-#endif
+    // Large grids: splitting every bank problem into n runs of frames so that the last, nearly empty round of workgroups gets
+    // shorter (cfg4 level 0: 3600 bank workgroups on 512 resident slots = 7.03 rounds) was modelled and measured in round 6
+    // (profiles/r06_attn_tail_split.txt): n = 2 gains 1.7 % at cfg4 level 0 and 3 % at its level 1, costs 5 % at cfg5 level 0
+    // and 3 % at cfg2 level 0; n = 5 loses everywhere (+5..14 %).  The rounds are not in lockstep, the source problems fill
+    // the tail, and the partial results' round trip costs more than the model allowed: no planner, the switch above stays.
     // TOKENFLOW_SPLIT_OVER=n (experiments): n further doublings once the chip is full -- shorter workgroups, so that a
     // launch running BESIDE this one (a rank's source branch on an auxiliary stream) is absorbed instead of appended
     static const int over = [] { const char* e = getenv("TOKENFLOW_SPLIT_OVER"); return e ? atoi(e) : 0; }();
@@ -1529,6 +1509,20 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     float m_run = -INFINITY;   // BOUND: deferred shift; else the lagged running maximum (raw-score units)
     const float lag = TF_ATTN_LAG / c;   // raw-score units
     float l_run = 0.f;         // !ONES: this lane's share of the denominator
+    // !ONES (Dh = 64: both P.V M-tiles are full, no spare row for the denominator): the row sum on the MATRIX pipe.  The 32 v_add of
+    // a tile were 2.0 of the loop's 7.8 VALU instructions per MFMA, on an issue port that is the kernel's limiter
+    // (profiles/r06_d64_accounting.md); v_mfma_f32_4x4x4 with A = ones adds the 4 rounded P values of a lane's register pair
+    // to a lane-local fp32 sum -- 8 short MFMAs (8 clocks of the pipe each) per tile, and the denominator sums exactly the
+    // rounded P the numerator multiplies.  TF_TUNE_IL_LSUM_VALU: the v_add form.
+#ifndef TF_TUNE_IL_LSUM_VALU
+    constexpr bool LSUM_MFMA = !ONES;
+#else
+    constexpr bool LSUM_MFMA = false;
+#endif
+    f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
+    vec4 ones4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ones4[j] = (E)1.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -1592,6 +1586,18 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
         const int r = un * 2;
         const f32x2 x = f32x2{s[X][r], s[X][r + 1]} * c2 - mc2;
         const float p0 = __builtin_amdgcn_exp2f(x[0]), p1 = __builtin_amdgcn_exp2f(x[1]);
+        if constexpr (LSUM_MFMA) {
+            // the register pair (4 values of P) completed by the PREVIOUS two units goes onto the lane's running sum: one unit
+            // late, so that the conversion that wrote the pair is not the instruction in front of the MFMA that reads it
+            // (VALU write -> MFMA read wait states); the last pair of a half is added by lsum_tail
+            if (un >= 2 && !(un & 1)) {
+                const vec8 v = pf[X][(un - 2) >> 2];
+                lacc = T::mfma4(ones4, ((un - 2) & 2) ? v.hi : v.lo, lacc);
+            }
+            pf[X][r >> 3][r & 7] = (E)p0;
+            pf[X][r >> 3][(r & 7) + 1] = (E)p1;
+            return;
+        }
         if constexpr (!ONES) {
             lsum += p0 + p1;
 #ifndef TF_TUNE_IL_LSUM_SINK
@@ -1606,12 +1612,40 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
 
     // One phase: the MFMAs of P.V half Hh of the current tile (V^T buffer vbuf) and -- NEXT -- of QK^T half Hh of the
     // next tile (K buffer kbuf), interleaved in program order with the softmax of half 1 - Hh (SM: there is one).
-    auto phase = [&](auto h_c, auto next_c, auto sm_c, int vbuf, int kbuf) {
+#ifndef TF_TUNE_IL_PF
+#define TF_TUNE_IL_PF 2
+#endif
+    constexpr int PF = TF_TUNE_IL_PF;   // fragment reads run PF steps ahead of their MFMA (register-staged Dh = 40 with 3: 132 VGPRs)
+    // LDS fragment i of the MFMA sequence of phase (Hh, NEXT): a P.V fragment of V^T buffer vbuf or a QK^T fragment of K buffer kbuf
+    auto frag = [&](auto h_c, auto next_c, int i, int vbuf, int kbuf) -> vec8 {
+        constexpr int Hh = decltype(h_c)::value;
+        constexpr IlSchedule<MT, C::KS, decltype(next_c)::value> sch{};
+        if (sch.is_pv[i]) {
+            const E* vbase = sV(vbuf) + l31 * VROW + (DMA == 1 ? 0 : Hh * 32 + 8 * hi);
+            if constexpr (DMA == 1)   // dense image: 16-B piece index of row (32 a + l31) is XOR-ed with row & 7
+                return __builtin_bit_cast(vec8, ld16(vbase + sch.a[i] * 32 * VROW + (((4 * Hh + hi + 2 * sch.b[i]) ^ (l31 & 7)) << 3)));
+            return __builtin_bit_cast(vec8, ld16(vbase + sch.a[i] * 32 * VROW + 16 * sch.b[i]));
+        }
+        return __builtin_bit_cast(vec8, ld16(sK(kbuf) + (Hh * 32 + l31) * KROW + 8 * hi + 16 * sch.a[i]));
+    };
+    // XPF (cross-phase prefetch): the first PF fragments of a phase that follows another one WITHOUT a barrier between them
+    // (the second phase of a tile: same buffers) are read during the last steps of its predecessor and handed over in
+    // fr_carry -- a phase otherwise opens with PF reads and a full LDS round trip in front of its first MFMA.
+#ifndef TF_TUNE_IL_NO_XPF
+    constexpr bool XPF = true;
+#else
+    constexpr bool XPF = false;
+#endif
+    vec8 fr_carry[PF];
+    auto phase = [&](auto h_c, auto next_c, auto sm_c, auto pre_in_c, auto pre_out_c, int vbuf, int kbuf) {
         constexpr int Hh = decltype(h_c)::value;
         constexpr int X = 1 - Hh;
         constexpr bool NEXT = decltype(next_c)::value, SM = decltype(sm_c)::value;
+        constexpr bool PRE_IN = XPF && decltype(pre_in_c)::value;     // fragments 0 .. PF-1 arrive in fr_carry
+        constexpr bool PRE_OUT = XPF && decltype(pre_out_c)::value;   // the following phase (half 1 - Hh, same NEXT, same buffers) gets its first PF
         constexpr IlSchedule<MT, C::KS, NEXT> sch{};
         constexpr int NM = sch.N;
+        static_assert(PF <= NM, "prefetch distance beyond one phase");
         bool move = false;
         float alpha = 1.f, lsum = 0.f;
         f32x2 c2 = {c, c}, mc2 = {0.f, 0.f};
@@ -1620,24 +1654,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
             const float mc = m_run * c;
             mc2 = f32x2{mc, mc};
         }
-        const E* vbase = sV(vbuf) + l31 * VROW + (DMA == 1 ? 0 : Hh * 32 + 8 * hi);
-        const E* kbase = sK(kbuf) + (Hh * 32 + l31) * KROW + 8 * hi;
-        const int vswz = l31 & 7;   // DMA form: 16-B piece index of row (32 a + l31) is XOR-ed with row & 7
-        auto frag = [&](int i) -> vec8 {
-            if (sch.is_pv[i]) {
-                if constexpr (DMA == 1)
-                    return __builtin_bit_cast(vec8, ld16(vbase + sch.a[i] * 32 * VROW + (((4 * Hh + hi + 2 * sch.b[i]) ^ vswz) << 3)));
-                return __builtin_bit_cast(vec8, ld16(vbase + sch.a[i] * 32 * VROW + 16 * sch.b[i]));
-            }
-            return __builtin_bit_cast(vec8, ld16(kbase + 16 * sch.a[i]));
-        };
-        constexpr int PF = 2;   // fragment reads run PF steps ahead of their MFMA (3 at Dh = 40: 132 VGPRs, one workgroup per CU)
         vec8 fr[NM];
 #pragma unroll
-        for (int i = 0; i < PF && i < NM; ++i) fr[i] = frag(i);
+        for (int i = 0; i < PF; ++i) fr[i] = PRE_IN ? fr_carry[i] : frag(h_c, next_c, i, vbuf, kbuf);
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
-            if (i + PF < NM) fr[i + PF] = frag(i + PF);
+            if (i + PF < NM) fr[i + PF] = frag(h_c, next_c, i + PF, vbuf, kbuf);
+            else if constexpr (PRE_OUT) fr_carry[i + PF - NM] = frag(std::integral_constant<int, X>{}, next_c, i + PF - NM, vbuf, kbuf);
             if (sch.is_pv[i]) {
                 o[sch.a[i]] = T::mfma32(fr[i], pf[Hh][sch.b[i]], o[sch.a[i]]);
             } else {
@@ -1654,14 +1677,16 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
             // P of half X must exist HERE (keeps the register-only softmax from sinking towards its consumer)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(pf[X][ks]));
+            if constexpr (LSUM_MFMA) lacc = T::mfma4(ones4, pf[X][1].hi, lacc);   // the last pair of the half (units 6, 7)
             // the shift moved: O (now including this phase's P.V, computed against the old shift) -- and the part of
             // the denominator accumulated so far, all of it at the old shift -- is rescaled before any P at the new
             // shift is multiplied in / added
             if (move) {
                 rescale(alpha);
-                if constexpr (!ONES) l_run *= alpha;
+                if constexpr (LSUM_MFMA) lacc *= alpha;
+                else if constexpr (!ONES) l_run *= alpha;
             }
-            if constexpr (!ONES) l_run += lsum;
+            if constexpr (!ONES && !LSUM_MFMA) l_run += lsum;
         }
     };
     typedef std::integral_constant<int, 0> H0;
@@ -1698,9 +1723,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
         float lsum = 0.f;
 #pragma unroll
         for (int un = 0; un < 8; ++un) sm_unit(H0{}, un, c2, mc2, lsum);
-        if constexpr (!ONES) l_run = lsum;
+        if constexpr (LSUM_MFMA) lacc = T::mfma4(ones4, pf[0][1].hi, lacc);
+        if constexpr (!ONES && !LSUM_MFMA) l_run = lsum;
     }
 
+#ifdef TF_TUNE_IL_PRIO
+    // A/B switch: static priority for the second-dispatched half of the workgroup's waves (cdna_hip_programming.md T5)
+    if (__builtin_amdgcn_readfirstlane(tid) >= NT / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     // All tiles but the last: every phase also runs the QK^T half of the NEXT tile.  The last tile is peeled (no
     // branch on "is there a next tile" inside the loop: the two shapes of the body would otherwise make the
     // compiler keep two copies of the O accumulators and copy between them).
@@ -1717,8 +1747,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
             __builtin_amdgcn_sched_barrier(0);   // last readers of Kbuf[cur] (K(t)) and Vbuf[nxt] (V(t-1)): free to refill
             if (t + 2 < ntiles) dma_k(cur);      // K(t+2)
             dma_v(nxt);                          // V(t+1)
-            phase(H0{}, Yes{}, Yes{}, cur, nxt);
-            phase(H1{}, Yes{}, Yes{}, cur, nxt);
+            phase(H0{}, Yes{}, Yes{}, No{}, Yes{}, cur, nxt);
+            phase(H1{}, Yes{}, Yes{}, Yes{}, No{}, cur, nxt);
             continue;
         }
         // Kbuf[nxt] held K(t-1) (last read by QK(t-1) in iteration t-2), Vbuf[cur] held V(t-2) (last read in iteration
@@ -1729,8 +1759,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
         load_v();                     // V(t+1)
         __syncthreads();              // K(t+1), V(t) visible to all waves
         __builtin_amdgcn_sched_barrier(0);
-        phase(H0{}, Yes{}, Yes{}, cur, nxt);   // O += V0(t) P0(t), S0(t+1)   ||  P1(t)
-        phase(H1{}, Yes{}, Yes{}, cur, nxt);   // O += V1(t) P1(t), S1(t+1)   ||  P0(t+1)
+        phase(H0{}, Yes{}, Yes{}, No{}, Yes{}, cur, nxt);   // O += V0(t) P0(t), S0(t+1)   ||  P1(t)
+        phase(H1{}, Yes{}, Yes{}, Yes{}, No{}, cur, nxt);   // O += V1(t) P1(t), S1(t+1)   ||  P0(t+1)
     }
     {
         const int cur = (ntiles - 1) & 1;
@@ -1738,14 +1768,16 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
         else write_v(cur);            // V(n-1)
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
-        phase(H0{}, No{}, Yes{}, cur, cur);    // O += V0 P0   ||  P1
-        phase(H1{}, No{}, No{}, cur, cur);     // O += V1 P1
+        phase(H0{}, No{}, Yes{}, No{}, Yes{}, cur, cur);    // O += V0 P0   ||  P1
+        phase(H1{}, No{}, No{}, Yes{}, No{}, cur, cur);     // O += V1 P1
     }
 
     // ---- epilogue
     float l_tot;
     if constexpr (ONES)
         l_tot = __shfl(o[MT - 1][ONES_R], l31);   // row VR of the V^T image is 1.0: sum of P from the MFMA
+    else if constexpr (LSUM_MFMA)
+        l_tot = lacc[0] + __shfl_xor(lacc[0], 32);
     else
         l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv_l = 1.0f / l_tot;

@@ -40,6 +40,8 @@ for stage in "$@"; do
                   env $e timeout 300 python tools/attn_microbench.py 10,9216,5,64 10,2304,10,64 25,4096,5,64 8,1024,8,80 8,4096,8,40 2>/dev/null | grep "inject=0" | tee -a $O/attn_tail_split.txt; done ;;
     wiremodel)  for a in "" "--wire-model 25,50" "--wire-model 10,100"; do timeout 600 python tools/rank_step_microbench.py --native --only split,auto --no-levels --reps 12 $a 2>/dev/null | grep -v "^  wire:" | tee -a $O/rank_step_wire.txt; done
                 timeout 300 python tools/rank_step_microbench.py --native --only split,auto --no-levels --no-copies --reps 12 2>/dev/null | tee -a $O/rank_step_wire.txt ;;
+    hooksbd)    for a in "cfg2 6 --graph" "cfg2 10 --ranks 8 --wire-less --graph" "cfg2 6 --ranks 1 --graph" "cfg2 6 --ranks 1 --split --graph"; do timeout 900 python tools/hooks_bench.py $a --breakdown 2>&1 | grep -v amdgpu.ids | tee -a $O/hooks_breakdown.txt; done
+                timeout 300 python tools/rank_step_microbench.py --native --only split,auto --no-copies --no-levels --reps 12 2>/dev/null | grep "step inject" | tee -a $O/hooks_breakdown.txt ;;
     seam2)      timeout 900 python -m pytest tests/test_driver_seam.py tests/test_sharded_gpu.py -m gpu -q --tb=short -p no:cacheprovider -s -k "driver or shard_vs_default" 2>&1 | grep -v "^$" | tail -60 > $O/seam2_tests.txt; grep -ai "driver seam\|passed\|failed\|Error\|assert" $O/seam2_tests.txt | cut -c1-300 ;;
     inputsab)   for n in 1 0 1 0; do timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-yardstick --no-parity --input-sets $n > $O/bench_sets_$n.json 2>> $O/inputsab.err; python -c "import json;d=json.load(open('$O/bench_sets_$n.json'));print('input sets',d['input_sets']['n'],d['ms_per_step'],d['ms_per_step_inject_on'],d['ms_per_step_inject_off'],d['roofline']['avg_launch_ms'])" | tee -a $O/input_sets_ab.txt; done ;;
     src4ab)     for lib in "" nosrc4 "" nosrc4; do echo "== lib=${lib:-current}" | tee -a $O/rank_step_src4_ab.txt

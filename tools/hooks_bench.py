@@ -16,6 +16,14 @@ calls the ops directly on pre-made tensors.
                     tools/rank_step_microbench.py --native (the same rank through bench.py's direct op calls).  With
                     --graph the rank's passes replay from HIP graphs (loopback exchanges are stream-ordered copies; the
                     pivotal pass ends with hooks.join_frame_shard): the hook-level rank step without Python issue time.
+                    --ranks 1: a WORLD-1 FrameShard registered through register_frame_shard (bit-stable attention mode
+                    unless --split): what the per-grid kernel choice it gives up costs on one GPU.
+      --breakdown   re-run this command under `rocprofv3 --kernel-trace --memory-copy-trace` and split the GPU time of a
+                    step into (i) the library's own launches (tf_*), (ii) what the hook layer adds around them (copies and
+                    dtype casts: torch copy kernels and device-to-device copies), (iii) the block's own layers (everything
+                    else: the residual adds `ff_output + hidden_states`, tokenflow_utils.py:427) -- per step, with the
+                    largest kernels of (ii) and (iii) named.  Compare (i) + (ii) on a rank with
+                    tools/rank_step_microbench.py --native --no-copies.
 """
 import os
 import sys
@@ -53,6 +61,7 @@ def build(cfg, dev, dtype):
     return holder, blocks
 
 
+RAW_ARGV = list(sys.argv)
 PROJ = "--proj" in sys.argv      # keep the real q/k/v/out Linear layers of attn1 (default: identities)
 GRAPH = "--graph" in sys.argv
 ALL_CHUNKS = "--all-chunks" in sys.argv
@@ -67,7 +76,66 @@ def _opt(name, default):
     return default
 
 
+TF_KERNELS = ("ext_attn", "attn_fused", "attn_merge", "vt_pack", "nn_search", "gather_blend", "gbn_", "layer_norm",
+              "add_layer_norm", "pivot_inv_norm", "head_pack", "head_unpack", "inject_copy", "ddim_step", "wire_hold")
+
+
+def breakdown():
+    """Re-run under rocprofv3 and classify the trace (see the module docstring)."""
+    import glob
+    import re
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    args = [a for a in sys.argv[1:] if a != "--breakdown"]
+    out = tempfile.mkdtemp(prefix="hooks_bd_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    r = subprocess.run(["rocprofv3", "--kernel-trace", "--memory-copy-trace", "-d", out, "--", sys.executable,
+                        os.path.abspath(__file__)] + args, cwd="/tmp", env=env, capture_output=True, text=True)
+    line = [l for l in r.stdout.splitlines() if l.startswith("hooks path")]
+    print(line[-1] if line else r.stdout[-400:] + r.stderr[-400:])
+    m = re.search(r"\[steps run: (\d+)\]", r.stdout)
+    n_steps = int(m.group(1)) if m else 1
+    dbs = glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True)
+    if not dbs:
+        print("no rocprofv3 database produced:", r.stderr[-300:])
+        return
+    cur = sqlite3.connect(dbs[0]).cursor()
+    cls = {"tf": {}, "hook": {}, "model": {}}
+    for name, dur in cur.execute("select name, duration from kernels"):
+        short = re.sub(r"\(anonymous namespace\)::", "", name)
+        if any(k in short for k in TF_KERNELS) and "at::native" not in short:
+            c = "tf"
+        elif "at::native" in short and re.search(r"copy|Copy|cast", short):
+            c = "hook"
+        else:
+            c = "model"
+        key = re.sub(r"\((?:[^()]|\([^()]*\))*\)$", "", short)[:100]
+        d = cls[c].setdefault(key, [0, 0.0])
+        d[0] += 1
+        d[1] += dur
+    tabs = [r_[0] for r_ in cur.execute("select name from sqlite_master where type in ('table','view')")]
+    for tab in ("memory_copies", "memory_copy"):
+        if tab in tabs:
+            for (dur,) in cur.execute(f"select end - start from {tab}"):
+                d = cls["hook"].setdefault("device-to-device copy (hipMemcpyAsync)", [0, 0.0])
+                d[0] += 1
+                d[1] += dur
+            break
+    tot = {c: sum(v[1] for v in cls[c].values()) / n_steps / 1e6 for c in cls}
+    print(f"GPU time per step over {n_steps} traced steps (kernel durations summed; idle gaps are in none of the three): "
+          f"(i) library launches {tot['tf']:.3f} ms | (ii) hook-added copies / casts {tot['hook']:.3f} ms | "
+          f"(iii) the block's own layers {tot['model']:.3f} ms | (i)+(ii) = {tot['tf'] + tot['hook']:.3f} ms")
+    for c, title in (("hook", "(ii) hook-added"), ("model", "(iii) block's own")):
+        for key, (cnt, dur) in sorted(cls[c].items(), key=lambda kv: -kv[1][1])[:4]:
+            print(f"   {title}: {dur / n_steps / 1e6:7.3f} ms/step  {cnt / n_steps:6.1f} launches/step  {key}")
+    shutil.rmtree(out, ignore_errors=True)
+
+
 def main():
+    if "--breakdown" in sys.argv:
+        return breakdown()
     ranks, rank = _opt("--ranks", 1), _opt("--rank", 1)
     wireless = "--wire-less" in sys.argv
     argv = [a for a in sys.argv[1:] if not a.startswith("--")]
@@ -90,6 +158,10 @@ def main():
                                     HipComm.loopback(rank, ranks, copies=not wireless), attn_split="--one-pass" not in sys.argv)
         hooks.register_frame_shard(holder, shard)
         Kq, chunks = shard.Kl, list(range(shard.kf0, shard.kf0 + shard.Kl))
+    elif "--ranks" in RAW_ARGV:      # --ranks 1: a world-1 shard through register_frame_shard
+        from tokenflow_amd import sharded
+        shard = sharded.FrameShard(K, attn_split="--split" in sys.argv)
+        hooks.register_frame_shard(holder, shard)
     g = torch.Generator(device=dev).manual_seed(0)
     xs_piv = [torch.randn(3 * Kq, cfg.levels[l][0], cfg.levels[l][1], generator=g, device=dev, dtype=dtype)
               for _, l, _ in blocks]
@@ -148,8 +220,11 @@ def main():
     torch.cuda.synchronize()
     t = time.perf_counter() - t0
     mode = ("graph replay" if GRAPH else "eager") + (", one pass over all chunks" if ALL_CHUNKS else "") + (", real projections" if PROJ else "")
-    if shard is not None:
+    if shard is not None and ranks > 1:
         mode += f", rank {rank} of {ranks} (native executor, loopback transport{' without copies' if wireless else ''})"
+    elif shard is not None:
+        mode += f", world-1 FrameShard registered ({'split' if shard.attn_split else 'bit-stable'} attention mode)"
+    print(f"[steps run: {steps + 2}]")
     print(f"hooks path [{mode}], {cfg.name}: {t / steps * 1e3:.2f} ms/step ({cfg.frames * steps / t:.0f} frames/s); "
           f"host-side issue time {t_cpu / steps * 1e3:.2f} ms/step")
 
