@@ -1298,7 +1298,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     constexpr int VR = PACK ? 2 * DH : DH;              // staged V^T rows per tile
     constexpr int MT = PACK ? 3 : C::MT;                // P.V M-tiles
     static_assert(DMA != 1 || (!PACK && (64 * DH * 2) % 1024 == 0 && (VR * 128) % 1024 == 0), "dense DMA form: whole 1 KB pieces");
-    static_assert(DMA == 0 || !PACK, "the DMA forms stage one bank");
+    static_assert(DMA != 1 || !PACK, "the dense DMA form stages one bank");
     constexpr int KROW = DMA == 1 ? DH : C::KROW;       // LDS row strides (elements): dense images in the DMA = 1 form
     constexpr int VROW = DMA == 1 ? 64 : C::VROW;
     constexpr int K_ELEMS = 64 * KROW;
@@ -1467,7 +1467,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
             const int row = min(o / (2 * VROW), VR - 1);
             const int sl = (o - row * 2 * VROW) >> 4;
             dv_ok[n] = o < V_IMG;
-            dv_goff[n] = (uint32_t)(row * (int)vt_row + ((DMA == 1 ? sl ^ (row & 7) : sl < 8 ? sl : 0) << 3)) * 2u;
+            // image row -> V^T row: bank row / DH (the next branch's rows lie H*DH V^T rows further), feature row % DH
+            const int vrow = PACK ? (row / DH) * H * DH + row % DH : row;
+            dv_goff[n] = (uint32_t)(vrow * (int)vt_row + ((DMA == 1 ? sl ^ (row & 7) : sl < 8 ? sl : 0) << 3)) * 2u;
         }
     }
     auto dma_k = [&](int buf) {      // the next K tile -> Kbuf[buf]
@@ -1953,7 +1955,17 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
                 return compose([&] { return launch_il<T, 40, 8, MODE_ALL, 4, TF_TUNE_IL40_DMA>(p, st); },
                                [&] {
 #ifndef TF_TUNE_NO_IL40_DUAL
-                                   if (p.S >= 256 && p.S % 64 == 0) return launch_il<T, 40, 4, MODE_DUAL, 3>(p, st);
+#ifndef TF_TUNE_IL40_DUAL_DMA
+#define TF_TUNE_IL40_DUAL_DMA 0
+#endif
+#ifndef TF_TUNE_IL40_DUAL_NW
+#define TF_TUNE_IL40_DUAL_NW 4
+#endif
+#ifndef TF_TUNE_IL40_DUAL_MINW
+#define TF_TUNE_IL40_DUAL_MINW 3
+#endif
+                                   if (p.S >= 256 && p.S % 64 == 0)
+                                       return launch_il<T, 40, TF_TUNE_IL40_DUAL_NW, MODE_DUAL, TF_TUNE_IL40_DUAL_MINW, TF_TUNE_IL40_DUAL_DMA>(p, st);
 #endif
                                    return launch_one<T, DH, 1, 4, MODE_DUAL, 3, false>(p, st);
                                },

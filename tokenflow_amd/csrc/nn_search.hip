@@ -615,8 +615,12 @@ __global__ __launch_bounds__(256, 3) void nn_search_rb_kernel(const typename T::
 // the fragment reads (32 rows, 640-B stride) are avoided by an XOR swizzle of the 16-B piece index with (row >> 1) & 7,
 // applied on the SOURCE address of the DMA and on the read (the same involution; it permutes inside aligned groups of
 // 8 pieces, D / 8 being a multiple of 8).  Same arithmetic as nn_search_rbg_kernel.
-template <typename T, int DK>
-__global__ __launch_bounds__(256, 3) void nn_search_rbg_kernel(const typename T::elem* __restrict__ tgt,
+// TT = target tiles (of 32 rows) per wave.  TT = 2 (round 6): a wave keeps 64 targets in registers (160 VGPRs of B fragments),
+// every pivot fragment read from LDS feeds TWO MFMAs on two independent accumulator chains, and a barrier interval carries
+// twice the matrix work -- half the LDS traffic and half the barriers per MFMA; 2 waves per SIMD instead of 3.  The
+// arithmetic of a (target, pivot) pair is unchanged (same contraction order): the kernels are interchangeable bit for bit.
+template <typename T, int DK, int TT = 1>
+__global__ __launch_bounds__(256, TT == 1 ? 3 : 2) void nn_search_rbg_kernel(const typename T::elem* __restrict__ tgt,
                                                            const typename T::elem* __restrict__ piv,
                                                            const float* __restrict__ inv_norm,
                                                            int32_t* __restrict__ idx_out,
@@ -648,17 +652,21 @@ __global__ __launch_bounds__(256, 3) void nn_search_rbg_kernel(const typename T:
     const E* pv = piv + (int64_t)kf * S * D;
     const float* inv = inv_norm + (int64_t)kf * S;
     const int64_t t_end = (chunk + 1) * ch.nS;
-    const int64_t t_row = chunk * ch.nS + (int64_t)(blockIdx.x - chunk * ch.ppc) * 128 + wave * 32 + l31;
+    int64_t t_row[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+        t_row[tt] = chunk * ch.nS + (int64_t)(blockIdx.x - chunk * ch.ppc) * (128 * TT) + (wave * TT + tt) * 32 + l31;
 
     const int n_mt_all = (S + TMR - 1) / TMR;
     const int mt0 = blockIdx.z * tiles_per_split;
     const int n_mt = min(tiles_per_split, n_mt_all - mt0);
 
-    vec8 fb[DK];
-    {
-        const E* tp = tgt + (t_row < t_end ? t_row : t_end - 1) * D + 8 * hi;
+    vec8 fb[TT][DK];
 #pragma unroll
-        for (int t = 0; t < DK; ++t) fb[t] = __builtin_bit_cast(vec8, ld16(tp + 16 * t));
+    for (int tt = 0; tt < TT; ++tt) {
+        const E* tp = tgt + (t_row[tt] < t_end ? t_row[tt] : t_end - 1) * D + 8 * hi;
+#pragma unroll
+        for (int t = 0; t < DK; ++t) fb[tt][t] = __builtin_bit_cast(vec8, ld16(tp + 16 * t));
     }
 
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -689,8 +697,10 @@ __global__ __launch_bounds__(256, 3) void nn_search_rbg_kernel(const typename T:
         if (tid < TMR) sInv[(mt & 1) * TMR + tid] = rinv;
     };
 
-    float best_v = -INFINITY;
-    int best_i = 0;
+    float best_v[TT];
+    int best_i[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) best_v[tt] = -INFINITY, best_i[tt] = 0;
     stage_load(0);
     stage_write(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -698,40 +708,54 @@ __global__ __launch_bounds__(256, 3) void nn_search_rbg_kernel(const typename T:
     for (int mt = 0; mt < n_mt; ++mt) {
         const bool has_next = mt + 1 < n_mt;
         if (has_next) stage_load(mt + 1);
-        f32x16 acc;
+        f32x16 acc[TT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
         const E* arow = sA(mt & 1) + l31 * RS;
         const int swz = (l31 >> 1) & 7;
 #pragma unroll
-        for (int t = 0; t < DK; ++t)
-            acc = T::mfma32(__builtin_bit_cast(vec8, ld16(arow + (((2 * t + hi) ^ swz) << 3))), fb[t], acc);
+        for (int t = 0; t < DK; ++t) {
+            const vec8 fa = __builtin_bit_cast(vec8, ld16(arow + (((2 * t + hi) ^ swz) << 3)));
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) acc[tt] = T::mfma32(fa, fb[tt][t], acc[tt]);
+        }
         const float* si = sInv + (mt & 1) * TMR;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rl = cd_row(r, hi);
-            const float sc = acc[r] * si[rl];
-            if (sc > best_v) {
-                best_v = sc;
-                best_i = (mt0 + mt) * TMR + rl;
+            const float w = si[rl];
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                const float sc = acc[tt][r] * w;
+                if (sc > best_v[tt]) {
+                    best_v[tt] = sc;
+                    best_i[tt] = (mt0 + mt) * TMR + rl;
+                }
             }
         }
         if (has_next) stage_write(mt + 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    const float ov = __shfl_xor(best_v, 32);
-    const int oi = __shfl_xor(best_i, 32);
-    if (ov > best_v || (ov == best_v && oi < best_i)) {
-        best_v = ov;
-        best_i = oi;
-    }
-    best_i = best_i < S ? best_i : S - 1;
-    if (hi == 0 && t_row < t_end) {
-        if (part_out)
-            part_out[((int64_t)blockIdx.z * gridDim.y + p) * n_tgt + t_row] = NnPartial{best_v, best_i};
-        else
-            idx_out[(int64_t)p * n_tgt + t_row] = best_i;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+        const float ov = __shfl_xor(best_v[tt], 32);
+        const int oi = __shfl_xor(best_i[tt], 32);
+        float bv = best_v[tt];
+        int bi = best_i[tt];
+        if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+        }
+        bi = bi < S ? bi : S - 1;
+        if (hi == 0 && t_row[tt] < t_end) {
+            if (part_out)
+                part_out[((int64_t)blockIdx.z * gridDim.y + p) * n_tgt + t_row[tt]] = NnPartial{bv, bi};
+            else
+                idx_out[(int64_t)p * n_tgt + t_row[tt]] = bi;
+        }
     }
 }
 
@@ -751,6 +775,7 @@ __global__ __launch_bounds__(256) void nn_finalize_kernel(const NnPartial* __res
 // Launch plan shared by the launchers and tf_nn_search_workspace_bytes.
 enum NnKernel {
     NN_RB,      // register-B kernel (D == 320): 128-target panels, 32-pivot tiles
+    NN_RB2,     // the same with two target tiles per wave (256-target panels): chip-filling grids, S % 32 == 0
     NN_WIDE,    // generic kernel, 128-target panels, 64-wide D chunks
     NN_BK64,    // generic kernel, 64-target panels, 64-wide D chunks
     NN_BK128,   // few workgroups and a long contraction: 128-wide D chunks
@@ -817,6 +842,15 @@ static NnPlan nn_plan(int64_t n_tgt, int S, int D, int P, int C = 1) {
     }
 #endif
     if (D == 320) {
+#ifndef TF_TUNE_NN_NO_RB2
+        // two target tiles per wave where the launch still has >= 4 rounds of its 512 resident workgroups (2 per CU)
+        static const int rb2_min = [] { const char* e = getenv("TF_NN_RB2_MIN_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2048; }();
+        static const bool dma_ok = [] { const char* e = getenv("TF_NN_RB_GLDS"); return !e || atoi(e) != 0; }();
+        if (dma_ok && S % 32 == 0 && shape(256, 32) >= rb2_min) {
+            pl.kern = NN_RB2;
+            return pl;
+        }
+#endif
         pl.kern = NN_RB;
         shape(128, 32);
         return pl;
@@ -895,6 +929,14 @@ int launch_nn_rb(const void* tgt, const void* piv, const float* inv_norm, int32_
     const int splits = pl.splits, tps = pl.tiles_per_split;
     dim3 grid((unsigned)(pl.panels * C), (unsigned)P, (unsigned)splits);
     const NnChunks ch{n_tgt, (int)pl.panels, first_single};
+    if (pl.kern == NN_RB2) {   // 256-target panels, two target tiles per wave (the plan has checked S % 32 == 0)
+        const size_t lds_g = 2 * 32 * D * 2 + 2 * 32 * 4;
+        hipLaunchKernelGGL((nn_search_rbg_kernel<T, DK, 2>), grid, dim3(256), lds_g, st,
+                           reinterpret_cast<const typename T::elem*>(tgt), reinterpret_cast<const typename T::elem*>(piv),
+                           inv_norm, idx, (splits > 1 || !fin) ? ws : nullptr, n_tgt * C, S, kf0, kf1, tps, ch);
+        TF_LAUNCH_CHECK("tf_nn_search");
+        return (fin && splits > 1) ? finalize(ws, idx, n_tgt * C * P, splits, st) : 0;
+    }
     // pivot tiles by LDS-DMA where every tile is full (S % 32 == 0): +1.4 % at cfg2 / cfg4 level 0
     // (profiles/r05_nn_glds_ab.txt: 1028 -> 1014 us, 8826 -> 8746 us per block); TF_NN_RB_GLDS=0: the register-staged kernel
     static const bool dma = [] { const char* e = getenv("TF_NN_RB_GLDS"); return !e || atoi(e) != 0; }();
@@ -918,6 +960,7 @@ int dispatch_nn(const void* tgt, const void* piv, const float* inv_norm, int32_t
                 int S, int D, int P, int kf0, int kf1, hipStream_t st, bool fin, int C = 1, int first_single = 0) {
     switch (nn_plan(n_tgt, S, D, P, C).kern) {
         case NN_RB:
+        case NN_RB2:
             return launch_nn_rb<T, 20>(tgt, piv, inv_norm, idx, ws, n_tgt, S, P, kf0, kf1, st, fin, C, first_single);
         case NN_GLDS:
             return launch_nn_glds<T>(tgt, piv, inv_norm, idx, ws, n_tgt, S, D, P, kf0, kf1, st, fin, C, first_single);

@@ -42,6 +42,17 @@ for stage in "$@"; do
                 timeout 300 python tools/rank_step_microbench.py --native --only split,auto --no-levels --no-copies --reps 12 2>/dev/null | tee -a $O/rank_step_wire.txt ;;
     hooksbd)    for a in "cfg2 6 --graph" "cfg2 10 --ranks 8 --wire-less --graph" "cfg2 6 --ranks 1 --graph" "cfg2 6 --ranks 1 --split --graph"; do timeout 900 python tools/hooks_bench.py $a --breakdown 2>&1 | grep -v amdgpu.ids | tee -a $O/hooks_breakdown.txt; done
                 timeout 300 python tools/rank_step_microbench.py --native --only split,auto --no-copies --no-levels --reps 12 2>/dev/null | grep "step inject" | tee -a $O/hooks_breakdown.txt ;;
+    r6ab2)      # round 6, second A/B: cross-phase prefetch, prefetch distance, static priority, denominator on the matrix pipe
+                timeout 120 tools/ubench/mfma4_probe > $O/mfma4_probe.txt 2>&1; cat $O/mfma4_probe.txt
+                for lib in noxpfvalu "" lsumvalu noxpf pf3 prio noxpfvalu ""; do echo "== lib=${lib:-default}" | tee -a $O/attn_il_ab2.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 10,9216,5,64 25,4096,5,64 10,2304,10,64 8,4096,8,40 8,1024,8,80 2>/dev/null | grep "inject=0" | tee -a $O/attn_il_ab2.txt; done ;;
+    d64tests)   timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_baseline_configs_gpu.py tests/test_fullsize_gpu.py -q --tb=short -p no:cacheprovider -k "attn or cfg4 or cfg5 or cfg2" 2>&1 | tail -8 | tee -a $O/d64_tests.txt ;;
+    dualab)     for lib in "" dualdma dualdma4 dualdma8 "" dualdma; do echo "== lib=${lib:-default}" | tee -a $O/attn_d40_dual_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 8,4096,8,40 4,1024,8,40 2>/dev/null | grep "inject=1" | tee -a $O/attn_d40_dual_ab.txt; done ;;
+    rb2ab)      for e in "TF_NN_RB2_MIN_WGS=100000000" "X=0" "TF_NN_RB2_MIN_WGS=100000000" "X=0"; do echo "== $e (X=0: two target tiles per wave where the plan takes them)" | tee -a $O/nn_rb2_ab.txt
+                  env $e timeout 300 python tools/prop_microbench.py 8,5,4096,320 10,8,9216,320 25,8,4096,320 2>/dev/null | grep "one call" | tee -a $O/nn_rb2_ab.txt
+                  env $e timeout 300 python tools/nn_microbench.py 8,5,4096,320 10,8,9216,320 2>/dev/null | tee -a $O/nn_rb2_ab.txt; done
+                timeout 900 python -m pytest tests/test_fullsize_gpu.py tests/test_kernels_gpu.py tests/test_baseline_configs_gpu.py -q --tb=short -p no:cacheprovider -k "nn_search or propagat or cfg2 or cfg4" 2>&1 | tail -4 | tee -a $O/nn_rb2_ab.txt ;;
     seam2)      timeout 900 python -m pytest tests/test_driver_seam.py tests/test_sharded_gpu.py -m gpu -q --tb=short -p no:cacheprovider -s -k "driver or shard_vs_default" 2>&1 | grep -v "^$" | tail -60 > $O/seam2_tests.txt; grep -ai "driver seam\|passed\|failed\|Error\|assert" $O/seam2_tests.txt | cut -c1-300 ;;
     inputsab)   for n in 1 0 1 0; do timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-yardstick --no-parity --input-sets $n > $O/bench_sets_$n.json 2>> $O/inputsab.err; python -c "import json;d=json.load(open('$O/bench_sets_$n.json'));print('input sets',d['input_sets']['n'],d['ms_per_step'],d['ms_per_step_inject_on'],d['ms_per_step_inject_off'],d['roofline']['avg_launch_ms'])" | tee -a $O/input_sets_ab.txt; done ;;
     src4ab)     for lib in "" nosrc4 "" nosrc4; do echo "== lib=${lib:-current}" | tee -a $O/rank_step_src4_ab.txt
