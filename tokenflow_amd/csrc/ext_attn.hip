@@ -769,7 +769,7 @@ static int split_plan(int K, int Kq, int S, int H, int Dh, bool inject, int part
 #ifndef TF_TUNE_OCC160
 #define TF_TUNE_OCC160 1   // splitting towards 2 waves per SIMD (the single-buffered tiles would allow two workgroups per
 #endif                     // CU) measured slower: 88 vs 85 us at cfg2 level 2, 41 vs 33 us on a rank of 8 (merge included)
-    const int occ = Dh == 40 ? (dual ? 3 : 4) : Dh == 160 ? TF_TUNE_OCC160 : (dual ? 2 : 3);   // waves per SIMD the kernels reach
+    const int occ = Dh == 40 ? 4 : Dh == 160 ? TF_TUNE_OCC160 : dual ? 2 : Dh == 64 ? 4 : 3;   // waves per SIMD the kernels reach
     const int64_t wgs = (int64_t)(dual ? 1 : 2) * Kq * ((S + 127) / 128) * H;   // 4-wave workgroups
     const int tpf = (S + 63) / 64;
     if (K * tpf < 16) return 1;   // a bank of a few tiles: the merge launch costs more than it buys (8x8 level)
@@ -1294,9 +1294,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     // ext_attn_kernel's PACK form, so the only differences to the single-bank kernel are the number of staged V^T rows
     // (VR), the number of P.V M-tiles (MT) and the epilogue's row -> (bank, feature) decode.
     constexpr bool PACK = MODE == MODE_DUAL;
-    static_assert(!PACK || DH == 40, "the packed dual-V image is a Dh = 40 form");
+    static_assert(!PACK || DH == 40 || DH == 64, "the packed dual-V image: Dh = 40 (3 M-tiles, ones row 80) or Dh = 64 (4 full M-tiles)");
     constexpr int VR = PACK ? 2 * DH : DH;              // staged V^T rows per tile
-    constexpr int MT = PACK ? 3 : C::MT;                // P.V M-tiles
+    constexpr int MT = PACK ? (2 * DH + 31) / 32 : C::MT;   // P.V M-tiles
     static_assert(DMA != 1 || (!PACK && (64 * DH * 2) % 1024 == 0 && (VR * 128) % 1024 == 0), "dense DMA form: whole 1 KB pieces");
     static_assert(DMA != 1 || !PACK, "the dense DMA form stages one bank");
     constexpr int KROW = DMA == 1 ? DH : C::KROW;       // LDS row strides (elements): dense images in the DMA = 1 form
@@ -1834,7 +1834,7 @@ template <typename T, int DH, int NW, int MODE, int MINW, int DMA = 0>
 int launch_il(AttnParams p, hipStream_t st) {
     typedef AttnCfg<DH, 64> C;
     constexpr size_t lds = DMA == 1            ? 2 * (size_t)(64 * DH + C::MT * 32 * 64) * 2 + 16   // dense images (+ the K over-read)
-                           : MODE == MODE_DUAL ? 2 * (size_t)(C::K_ELEMS + 96 * C::VROW) * 2        // packed dual-V image
+                           : MODE == MODE_DUAL ? 2 * (size_t)(C::K_ELEMS + ((2 * DH + 31) / 32) * 32 * C::VROW) * 2   // packed dual-V image
                                                : C::lds_bytes(1);
     auto kern = ext_attn_il_kernel<T, DH, NW, MODE, MINW, DMA>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1955,14 +1955,17 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
                 return compose([&] { return launch_il<T, 40, 8, MODE_ALL, 4, TF_TUNE_IL40_DMA>(p, st); },
                                [&] {
 #ifndef TF_TUNE_NO_IL40_DUAL
+                                   // Round 6: the packed dual-V kernel with LDS-DMA staging, 8-wave workgroups, FOUR waves per SIMD (128
+                                   // VGPRs; the register-staged 4-wave form needs 168 = 3 per SIMD): 2.54 against 2.81 ms at cfg2 level 0
+                                   // (profiles/r06_attn_d40_dual_ab.txt; DMA alone at 3 waves per SIMD: 2.70)
 #ifndef TF_TUNE_IL40_DUAL_DMA
-#define TF_TUNE_IL40_DUAL_DMA 0
+#define TF_TUNE_IL40_DUAL_DMA 2
 #endif
 #ifndef TF_TUNE_IL40_DUAL_NW
-#define TF_TUNE_IL40_DUAL_NW 4
+#define TF_TUNE_IL40_DUAL_NW 8
 #endif
 #ifndef TF_TUNE_IL40_DUAL_MINW
-#define TF_TUNE_IL40_DUAL_MINW 3
+#define TF_TUNE_IL40_DUAL_MINW 4
 #endif
                                    if (p.S >= 256 && p.S % 64 == 0)
                                        return launch_il<T, 40, TF_TUNE_IL40_DUAL_NW, MODE_DUAL, TF_TUNE_IL40_DUAL_MINW, TF_TUNE_IL40_DUAL_DMA>(p, st);
@@ -2029,7 +2032,15 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
         return compose([&] { return il ? launch_il<T, DH, TF_TUNE_IL64_NW, MODE_ALL, TF_TUNE_IL64_MINW, TF_TUNE_IL64_DMA>(p, st)
                                   : (p.S >= 512 && p.nseg == 1) ? launch_pp<T, DH, MODE_ALL, 2>(p, st)   // ragged frames: ping-pong
                                                                 : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st); },
-                       [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st); },
+                       [&] {
+#ifdef TF_TUNE_IL64_DUAL
+#ifndef TF_TUNE_IL64_DUAL_NW
+#define TF_TUNE_IL64_DUAL_NW 8
+#endif
+                                // A/B switch: the interleaved kernel with both V banks in one 4-M-tile image (uncond rows 0-63, cond 64-127)
+                                if (il) return launch_il<T, DH, TF_TUNE_IL64_DUAL_NW, MODE_DUAL, 2, 2>(p, st);
+#endif
+                                return launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st); },
                        [&] { return il ? launch_il<T, DH, TF_TUNE_IL64_NW, MODE_SOURCE, TF_TUNE_IL64_MINW, TF_TUNE_IL64_DMA>(p, st)
                                        : launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st); });
     } else if constexpr (DH == 80) {
