@@ -866,9 +866,9 @@ def main():
             traffic_src = tj.get("source")
         except Exception:
             traffic = None
-    kname = {40: "ext_attn_il_kernel<BF16, 40, 8, MODE_ALL, 4> (half-tile interleaved)",
-             64: "ext_attn_pp_kernel<BF16, 64, MODE_ALL, 2> (ping-pong)",
-             80: "ext_attn_il_kernel<BF16, 80, 8, MODE_ALL, 2> (half-tile interleaved)"}.get(
+    kname = {40: "ext_attn_il_kernel<BF16, 40, 8, MODE_ALL, 4, 2> (half-tile interleaved, LDS-DMA staged tiles)",
+             64: "ext_attn_il_kernel<BF16, 64, 8, MODE_ALL, 4, 2> (half-tile interleaved, LDS-DMA staged tiles, score bound)",
+             80: "ext_attn_il_kernel<BF16, 80, 4, MODE_ALL, 3, 2> (half-tile interleaved, LDS-DMA staged tiles)"}.get(
                  dh0, "ext_attn_kernel<BF16, %d, ..., MODE_ALL>" % dh0)
     plain = roof(False, blk0.attn_flops, {
         "kernel": kname + ", level 0, no q/k injection (+ vt_pack_kernel pre-pass inside the event bracket; N = 1 name: "
@@ -877,7 +877,7 @@ def main():
         "traffic_source": traffic_src or "profiles/traffic.json (rocprofv3 --pmc passes of tools/attn_microbench.py; "
                                          "not measured in this run)"})
     dual = roof(True, blk0.attn_flops, {
-        "kernel": ("ext_attn_il_kernel<BF16, 40, 4, MODE_DUAL, 3>" if dh0 == 40 else "the dual-V kernel")
+        "kernel": ("ext_attn_il_kernel<BF16, 40, 8, MODE_DUAL, 4, 2>" if dh0 == 40 else "the dual-V kernel")
                   + " (uncond + cond share QK^T and the softmax) + source launch + V^T pre-pass, level 0, q/k injection on",
         "executed_gflop_per_launch": round(blk0.attn_flops_inject / 1e9, 1),
         "note": "achieved/frac use the ALGORITHMIC flops of the reference formulation; the launch executes fewer"})

@@ -326,6 +326,21 @@ def test_library_exports_every_declared_symbol():
     assert {n for n in exported if "tf_" in n} == declared, {n for n in exported if "tf_" in n} ^ declared
 
 
+def test_loopback_wire_model_is_a_loopback_only_switch():
+    """tf_comm_loopback_wire (ABI 7) configures the wire model of a LOOPBACK communicator (no launch, no GPU needed to set
+    it); any other handle is refused with TF_ERR_COMM."""
+    import ctypes
+    from tokenflow_amd import _lib
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.tf_comm_init_loopback(1, 8, ctypes.byref(h)) == 0
+    assert lib.tf_comm_loopback_wire(h, 25.0, 50.0) == 0
+    assert lib.tf_comm_loopback_wire(h, 0.0, 0.0) == 0            # off again
+    assert lib.tf_comm_loopback_copies(h, 0) == 0
+    assert lib.tf_comm_destroy(h) == 0
+    assert lib.tf_comm_loopback_wire(None, 25.0, 50.0) == _lib.TF_ERR_COMM and lib.tf_last_error()
+
+
 def test_comm_available_is_a_loader_only_probe():
     """tf_comm_available: 0 where RCCL and every entry point the library binds can be loaded, else TF_ERR_COMM with the
     reason in tf_last_error -- and no thread / socket either way (`bootstrap`'s pre-flight calls it on every rank;
@@ -387,3 +402,20 @@ def test_ddim_inversion_matches_reference_golden(tmp_path, monkeypatch, dtype, s
           "reconstructed")
     assert inversion.latents_save_path("latents", "2.1", "data/wolf.mp4", 500, 40) == \
         os.path.join("latents", "sd_2.1", "wolf", "steps_500", "nframes_40")       # preprocess.py:305-309
+
+
+def test_fp32_as_environment_switch_is_validated():
+    import os
+    """TOKENFLOW_FP32_AS accepts bf16 / f16 and their common spellings; anything else fails at import with a message that
+    names the variable (a bare KeyError before round 6)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import torch; from tokenflow_amd import ops; print(ops.FP32_AS)"
+    for val, want in (("fp16", "torch.float16"), ("BF16", "torch.bfloat16"), ("half", "torch.float16")):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, TOKENFLOW_FP32_AS=val),
+                           capture_output=True, text=True)
+        assert r.returncode == 0 and want in r.stdout, (val, r.stdout, r.stderr[-300:])
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, TOKENFLOW_FP32_AS="fp8"),
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "TOKENFLOW_FP32_AS" in r.stderr and "ValueError" in r.stderr

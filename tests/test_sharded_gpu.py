@@ -451,6 +451,45 @@ def test_loopback_transport_copies_switch():
         comm.close()
 
 
+def test_loopback_wire_model_holds_the_stream():
+    """tf_comm_loopback_wire (ABI 7): every exchange of a loopback communicator holds its stream for
+    latency + bytes on the busiest link / bandwidth -- the executed stand-in for the wire of tools/rank_step_microbench.py
+    --wire-model.  Data movement is unchanged; the model switches off again with (0, 0)."""
+    from tokenflow_amd import _lib
+    from tokenflow_amd.comm import HipComm
+    send = torch.arange(8 * 4096, device="cuda", dtype=torch.float32).view(8, 4096).bfloat16()   # 8 KB per peer
+
+    def timed(comm):
+        recv = torch.zeros_like(send)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        comm.all_to_all_rows(send, recv)          # warm-up (module load of the hold kernel)
+        torch.cuda.synchronize()
+        e0.record()
+        comm.all_to_all_rows(send, recv)
+        e1.record()
+        torch.cuda.synchronize()
+        assert torch.equal(recv, send)
+        return e0.elapsed_time(e1) * 1e3          # us
+
+    comm = HipComm.loopback(3, 8, wire=(2000.0, 0.008))    # 2 ms latency + 8 KB on a link at 8 MB/s = 1 ms more
+    t_wire = timed(comm)
+    assert 2900.0 <= t_wire <= 4500.0, t_wire
+    _lib.check(_lib.load().tf_comm_loopback_wire(comm._h, 0.0, 0.0), "tf_comm_loopback_wire")
+    assert timed(comm) < 500.0
+    # neighbour exchange: one link out, one link in -> max(sent, received) bytes
+    _lib.check(_lib.load().tf_comm_loopback_wire(comm._h, 1000.0, 0.0), "tf_comm_loopback_wire")
+    got = [torch.zeros(4096, device="cuda", dtype=torch.bfloat16)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    comm.sendrecv([send[0]], 4, got, 2)
+    e1.record()
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], send[0]) and 900.0 <= e0.elapsed_time(e1) * 1e3 <= 2500.0
+    comm.close()
+    plain = HipComm.loopback(0, 1)
+    plain.close()
+
+
 def _hooks_gpu_worker(rank, world, port, K, inject, native, ret):
     """The drop-in hooks sharded over ranks (register_frame_shard) with the REAL kernels under autocast: each rank's
     block outputs equal the one-process hooks' bit for bit."""

@@ -72,6 +72,8 @@ enum { MODE_ALL = 0, MODE_SOURCE = 1, MODE_DUAL = 2 };
 constexpr bool attn_has_bound(int dh) {
 #ifdef TF_TUNE_NO_BOUND64
     return dh == 40;
+#elif defined(TF_TUNE_BOUND80)
+    return dh == 40 || dh == 64 || dh == 80;
 #else
     return dh == 40 || dh == 64;
 #endif
