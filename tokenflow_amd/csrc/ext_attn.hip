@@ -2035,11 +2035,14 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
                                   : (p.S >= 512 && p.nseg == 1) ? launch_pp<T, DH, MODE_ALL, 2>(p, st)   // ragged frames: ping-pong
                                                                 : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st); },
                        [&] {
-#ifdef TF_TUNE_IL64_DUAL
+#ifndef TF_TUNE_NO_IL64_DUAL
 #ifndef TF_TUNE_IL64_DUAL_NW
-#define TF_TUNE_IL64_DUAL_NW 8
+#define TF_TUNE_IL64_DUAL_NW 4
 #endif
-                                // A/B switch: the interleaved kernel with both V banks in one 4-M-tile image (uncond rows 0-63, cond 64-127)
+                                // Round 6: q/k injection in the interleaved kernel too -- both V banks in one 4-M-tile image (uncond rows
+                                // 0-63, cond 64-127), 12 MFMAs per phase against the same 8 softmax units, 162 VGPRs, 2 workgroups of 4 waves
+                                // per CU: 18.99 against 20.27 ms at cfg4 level 0, 2.47 / 2.61 at level 1, 0.359 / 0.380 at level 2
+                                // (profiles/r06_attn_d64_dual_ab.txt; 8-wave workgroups: 2.35 ms at level 1 but 0.46 at level 2)
                                 if (il) return launch_il<T, DH, TF_TUNE_IL64_DUAL_NW, MODE_DUAL, 2, 2>(p, st);
 #endif
                                 return launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st); },

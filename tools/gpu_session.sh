@@ -56,6 +56,12 @@ for stage in "$@"; do
     dual64ab)   for lib in "" il64dual8 il64dual4 "" il64dual8 il64dual4; do echo "== lib=${lib:-default}" | tee -a $O/attn_d64_dual_ab.txt
                   TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 10,9216,5,64 10,2304,10,64 10,576,20,64 2>/dev/null | grep "inject=1" | tee -a $O/attn_d64_dual_ab.txt; done
                 for lib in il64dual8 il64dual4; do TOKENFLOW_HIP_LIB=build/variants/lib_$lib.so timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_baseline_configs_gpu.py tests/test_fullsize_gpu.py -q --tb=short -p no:cacheprovider -k "attn or cfg4" 2>&1 | tail -4 | tee -a $O/attn_d64_dual_ab.txt; done ;;
+    benchab)    # whole-step A/B on ONE box: round 5's kernel choices rebuilt from this tree (build/variants/lib_r05eq.so) against the default
+                for lib in r05eq "" r05eq ""; do for cfg in cfg2 cfg4 cfg5; do
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 600 python bench.py --config $cfg --steps $([ $cfg = cfg2 ] && echo 10 || echo 2) --warmup 2 --no-cpu-baseline --no-yardstick --no-parity --no-other-configs > $O/benchab_tmp.json 2>> $O/benchab.err
+                  python -c "import json;d=json.load(open('$O/benchab_tmp.json'));print('lib=${lib:-default}', '$cfg', 'ms/step', d['ms_per_step'], 'inject on/off', d['ms_per_step_inject_on'], d['ms_per_step_inject_off'], 'L0 attn ms', d['roofline']['avg_launch_ms'])" | tee -a $O/bench_step_ab.txt; done; done ;;
+    bound80ab)  for lib in "" bound80 "" bound80; do echo "== lib=${lib:-default}" | tee -a $O/attn_d80_bound_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 8,1024,8,80 2>/dev/null | tee -a $O/attn_d80_bound_ab.txt; done ;;
     seam2)      timeout 900 python -m pytest tests/test_driver_seam.py tests/test_sharded_gpu.py -m gpu -q --tb=short -p no:cacheprovider -s -k "driver or shard_vs_default" 2>&1 | grep -v "^$" | tail -60 > $O/seam2_tests.txt; grep -ai "driver seam\|passed\|failed\|Error\|assert" $O/seam2_tests.txt | cut -c1-300 ;;
     inputsab)   for n in 1 0 1 0; do timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-yardstick --no-parity --input-sets $n > $O/bench_sets_$n.json 2>> $O/inputsab.err; python -c "import json;d=json.load(open('$O/bench_sets_$n.json'));print('input sets',d['input_sets']['n'],d['ms_per_step'],d['ms_per_step_inject_on'],d['ms_per_step_inject_off'],d['roofline']['avg_launch_ms'])" | tee -a $O/input_sets_ab.txt; done ;;
     src4ab)     for lib in "" nosrc4 "" nosrc4; do echo "== lib=${lib:-current}" | tee -a $O/rank_step_src4_ab.txt

@@ -88,7 +88,9 @@ def breakdown():
     import sqlite3
     import subprocess
     import tempfile
-    args = [a for a in sys.argv[1:] if a != "--breakdown"]
+    # eager on purpose: a graph capture runs an extra eager warm-up of every pass, which would blur the step count the sums
+    # are divided by; kernel durations do not depend on how a launch was issued
+    args = [a for a in sys.argv[1:] if a not in ("--breakdown", "--graph")]
     out = tempfile.mkdtemp(prefix="hooks_bd_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(["rocprofv3", "--kernel-trace", "--memory-copy-trace", "-d", out, "--", sys.executable,
