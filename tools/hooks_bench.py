@@ -107,6 +107,8 @@ def breakdown():
     cls = {"tf": {}, "hook": {}, "model": {}}
     for name, dur in cur.execute("select name, duration from kernels"):
         short = re.sub(r"\(anonymous namespace\)::", "", name)
+        if "distribution_elementwise" in short or "randperm" in short:
+            continue                       # this tool's own input generation (torch.randn before the first step)
         if any(k in short for k in TF_KERNELS) and "at::native" not in short:
             c = "tf"
         elif "at::native" in short and re.search(r"copy|Copy|cast", short):
@@ -129,8 +131,8 @@ def breakdown():
     print(f"GPU time per step over {n_steps} traced steps (kernel durations summed; idle gaps are in none of the three): "
           f"(i) library launches {tot['tf']:.3f} ms | (ii) hook-added copies / casts {tot['hook']:.3f} ms | "
           f"(iii) the block's own layers {tot['model']:.3f} ms | (i)+(ii) = {tot['tf'] + tot['hook']:.3f} ms")
-    for c, title in (("hook", "(ii) hook-added"), ("model", "(iii) block's own")):
-        for key, (cnt, dur) in sorted(cls[c].items(), key=lambda kv: -kv[1][1])[:4]:
+    for c, title, top in (("tf", "(i) library", 8), ("hook", "(ii) hook-added", 4), ("model", "(iii) block's own", 4)):
+        for key, (cnt, dur) in sorted(cls[c].items(), key=lambda kv: -kv[1][1])[:top]:
             print(f"   {title}: {dur / n_steps / 1e6:7.3f} ms/step  {cnt / n_steps:6.1f} launches/step  {key}")
     shutil.rmtree(out, ignore_errors=True)
 
