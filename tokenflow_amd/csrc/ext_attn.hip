@@ -1746,8 +1746,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     for (int t = 0; t + 1 < ntiles; ++t) {
         const int cur = t & 1, nxt = cur ^ 1;
         if constexpr (DMA != 0) {
+#if defined(TF_TUNE_IL_NOBARRIER_EXPERIMENT)   // timing experiments only (results are WRONG): what the per-tile rendezvous costs ...
+#elif defined(TF_TUNE_IL_NOWAIT_EXPERIMENT)      // ... and what the DMA drain in front of it costs (raw barrier, no vmcnt wait)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#else
             dma_wait();                   // this wave's pieces of K(t+1), V(t) have landed ...
             __syncthreads();              // ... everybody's have; every wave has left iteration t-1, whose phases were the
+#endif
             __builtin_amdgcn_sched_barrier(0);   // last readers of Kbuf[cur] (K(t)) and Vbuf[nxt] (V(t-1)): free to refill
             if (t + 2 < ntiles) dma_k(cur);      // K(t+2)
             dma_v(nxt);                          // V(t+1)

@@ -62,6 +62,9 @@ for stage in "$@"; do
                   python -c "import json;d=json.load(open('$O/benchab_tmp.json'));print('lib=${lib:-default}', '$cfg', 'ms/step', d['ms_per_step'], 'inject on/off', d['ms_per_step_inject_on'], d['ms_per_step_inject_off'], 'L0 attn ms', d['roofline']['avg_launch_ms'])" | tee -a $O/bench_step_ab.txt; done; done ;;
     bound80ab)  for lib in "" bound80 "" bound80; do echo "== lib=${lib:-default}" | tee -a $O/attn_d80_bound_ab.txt
                   TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 8,1024,8,80 2>/dev/null | tee -a $O/attn_d80_bound_ab.txt; done ;;
+    barrierexp) # timing experiments (WRONG results): the interleaved kernels without the per-tile barrier / without the DMA drain in front of it
+                for lib in "" nobar nowait "" nobar nowait; do echo "== lib=${lib:-default}" | tee -a $O/attn_barrier_experiment.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 10,9216,5,64 8,4096,8,40 8,1024,8,80 8,4096,8,80 2>/dev/null | grep "inject=0" | tee -a $O/attn_barrier_experiment.txt; done ;;
     seam2)      timeout 900 python -m pytest tests/test_driver_seam.py tests/test_sharded_gpu.py -m gpu -q --tb=short -p no:cacheprovider -s -k "driver or shard_vs_default" 2>&1 | grep -v "^$" | tail -60 > $O/seam2_tests.txt; grep -ai "driver seam\|passed\|failed\|Error\|assert" $O/seam2_tests.txt | cut -c1-300 ;;
     inputsab)   for n in 1 0 1 0; do timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-yardstick --no-parity --input-sets $n > $O/bench_sets_$n.json 2>> $O/inputsab.err; python -c "import json;d=json.load(open('$O/bench_sets_$n.json'));print('input sets',d['input_sets']['n'],d['ms_per_step'],d['ms_per_step_inject_on'],d['ms_per_step_inject_off'],d['roofline']['avg_launch_ms'])" | tee -a $O/input_sets_ab.txt; done ;;
     src4ab)     for lib in "" nosrc4 "" nosrc4; do echo "== lib=${lib:-current}" | tee -a $O/rank_step_src4_ab.txt
