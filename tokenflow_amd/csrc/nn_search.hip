@@ -843,10 +843,12 @@ static NnPlan nn_plan(int64_t n_tgt, int S, int D, int P, int C = 1) {
 #endif
     if (D == 320) {
 #ifndef TF_TUNE_NN_NO_RB2
-        // two target tiles per wave where the launch still has >= 4 rounds of its 512 resident workgroups (2 per CU)
-        static const int rb2_min = [] { const char* e = getenv("TF_NN_RB2_MIN_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2048; }();
+        // two target tiles per wave where the launch still has >= 2 rounds of its 512 resident workgroups (2 per CU) AND a
+        // workgroup streams >= 24 pivot tiles: its 160 VGPRs of target fragments are a fixed cost per workgroup (one chunk of
+        // cfg5, 32 tiles per workgroup: 196 -> 163 us; one chunk of cfg2, 16 tiles: 123 -> 125 us, profiles/r06_nn_rb2_ab.txt)
+        static const int rb2_min = [] { const char* e = getenv("TF_NN_RB2_MIN_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
         static const bool dma_ok = [] { const char* e = getenv("TF_NN_RB_GLDS"); return !e || atoi(e) != 0; }();
-        if (dma_ok && S % 32 == 0 && shape(256, 32) >= rb2_min) {
+        if (dma_ok && S % 32 == 0 && shape(256, 32) >= rb2_min && pl.tiles_per_split >= 24) {
             pl.kern = NN_RB2;
             return pl;
         }

@@ -104,12 +104,14 @@ def breakdown():
         print("no rocprofv3 database produced:", r.stderr[-300:])
         return
     cur = sqlite3.connect(dbs[0]).cursor()
-    cls = {"tf": {}, "hook": {}, "model": {}}
+    cls = {"tf": {}, "norm": {}, "hook": {}, "model": {}}
     for name, dur in cur.execute("select name, duration from kernels"):
         short = re.sub(r"\(anonymous namespace\)::", "", name)
         if "distribution_elementwise" in short or "randperm" in short:
             continue                       # this tool's own input generation (torch.randn before the first step)
-        if any(k in short for k in TF_KERNELS) and "at::native" not in short:
+        if "layer_norm" in short and "at::native" not in short:
+            c = "norm"                     # the block's own LayerNorms, run by the library (tf_layer_norm / tf_add_layer_norm)
+        elif any(k in short for k in TF_KERNELS) and "at::native" not in short:
             c = "tf"
         elif "at::native" in short and re.search(r"copy|Copy|cast", short):
             c = "hook"
@@ -128,10 +130,11 @@ def breakdown():
                 d[1] += dur
             break
     tot = {c: sum(v[1] for v in cls[c].values()) / n_steps / 1e6 for c in cls}
-    print(f"GPU time per step over {n_steps} traced steps (kernel durations summed; idle gaps are in none of the three): "
-          f"(i) library launches {tot['tf']:.3f} ms | (ii) hook-added copies / casts {tot['hook']:.3f} ms | "
-          f"(iii) the block's own layers {tot['model']:.3f} ms | (i)+(ii) = {tot['tf'] + tot['hook']:.3f} ms")
-    for c, title, top in (("tf", "(i) library", 8), ("hook", "(ii) hook-added", 4), ("model", "(iii) block's own", 4)):
+    print(f"GPU time per step over {n_steps} traced steps (kernel durations summed: launches that overlap on two streams count "
+          f"twice, idle gaps not at all): (i) the path's launches {tot['tf']:.3f} ms | (ii) hook-added copies / casts "
+          f"{tot['hook']:.3f} ms | (iii) the block's own layers {tot['model'] + tot['norm']:.3f} ms, of which its LayerNorms "
+          f"through tf_layer_norm {tot['norm']:.3f} | (i)+(ii) = {tot['tf'] + tot['hook']:.3f} ms")
+    for c, title, top in (("tf", "(i) path", 8), ("hook", "(ii) hook-added", 4), ("norm", "(iii) LayerNorm", 2), ("model", "(iii) block's own", 4)):
         for key, (cnt, dur) in sorted(cls[c].items(), key=lambda kv: -kv[1][1])[:top]:
             print(f"   {title}: {dur / n_steps / 1e6:7.3f} ms/step  {cnt / n_steps:6.1f} launches/step  {key}")
     shutil.rmtree(out, ignore_errors=True)
