@@ -873,7 +873,7 @@ def main():
     plain = roof(False, blk0.attn_flops, {
         "kernel": kname + ", level 0, no q/k injection (+ vt_pack_kernel pre-pass inside the event bracket; N = 1 name: "
                   "rocprofv3 prints the template arguments as <BF16; %d; ...; 0; ...>)" % dh0,
-        "traffic": traffic,
+        "traffic": traffic if world == 1 else None,      # the PMC figure is the single-GPU launch's, not a rank's
         "traffic_source": traffic_src or "profiles/traffic.json (rocprofv3 --pmc passes of tools/attn_microbench.py; "
                                          "not measured in this run)"})
     dual = roof(True, blk0.attn_flops, {
