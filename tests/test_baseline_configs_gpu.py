@@ -855,3 +855,18 @@ def test_ext_attn_interleaved_form_query_frame_subset(monkeypatch):
     full = ops.ext_attn(q, k, v, h, d ** -0.5, False).view(3, K, S, h * d)
     part = ops.ext_attn(q.view(3, K, S, h * d)[:, 2:4].reshape(6, S, h * d), k, v, h, d ** -0.5, False, q_frame0=2)
     assert torch.equal(part.view(3, 2, S, h * d), full[:, 2:4])
+
+
+@pytest.mark.parametrize("inject", [False, True])
+def test_ext_attn_d64_interleaved_query_frame_subset(inject, monkeypatch):
+    """Head dim 64 (BASELINE configs 4 / 5: 5 heads do not divide over 8 ranks, so a rank takes the bank exchange): the
+    queries of a frame subset against the full bank in the interleaved d = 64 kernel (LDS-DMA staged tiles, score bound,
+    matrix-pipe denominator; with injection the dual-V image) equal the matching slices of the full call, bit for bit."""
+    ops = _ops()
+    monkeypatch.setattr(ops, "NO_SPLIT", True)
+    K, S, h, d = 5, 1024, 5, 64
+    g = torch.Generator(device="cuda").manual_seed(13)
+    q, k, v = (torch.randn(3 * K, S, h * d, generator=g, device="cuda").bfloat16() for _ in range(3))
+    full = ops.ext_attn(q, k, v, h, d ** -0.5, inject).view(3, K, S, h * d)
+    part = ops.ext_attn(q.view(3, K, S, h * d)[:, 3:5].reshape(6, S, h * d), k, v, h, d ** -0.5, inject, q_frame0=3)
+    assert torch.equal(part.view(3, 2, S, h * d), full[:, 3:5])

@@ -217,6 +217,35 @@ def test_ext_attn_softmax_spike(d):
 
 @pytest.mark.parametrize("gain", [3.0, 12.0])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("K,S,h,d", [(2, 576, 2, 64), (3, 1024, 1, 64), (2, 576, 2, 40), (2, 576, 1, 80)])
+def test_ext_attn_d64_score_bound_shift_paths(K, S, h, d, dtype, gain):
+    """The interleaved streaming kernels on peaked logits (S a multiple of 64, >= 512; d = 40 and 80 for the same kernel
+    template with the denominator in a spare P.V row and, at 80, the lagged reference point instead of the bound).
+    Head dim 64 in the interleaved streaming kernel (S a multiple of 64, >= 512; round 6): the score bound skips the
+    per-tile maximum while |q| max|k| c - shift stays under its threshold; planted keys aligned with their queries make
+    the scores climb (gain 3: inside the bf16 headroom, no rescale after the first tile; gain 12, and f16 at either
+    gain: the bound fails, every half tile looks at its maximum and the deferred shift moves in late tiles -- O AND the
+    matrix-pipe denominator are rescaled).  Plain and q/k-injected (the 4-M-tile dual-V image), one-pass and split."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(29 + S + d)
+    q, k, v = (torch.randn(3 * K, S, h * d, generator=g) for _ in range(3))
+    for b in range(3 * K):
+        for s_ in range(0, S, 5):
+            k[b, (s_ * 3 + S - 60) % S] = q[b, s_] * gain      # many spikes land in the last 64-key tile of a frame
+    rnd = orc.bf16_round if dtype == torch.bfloat16 else (lambda x: x.half().float())
+    q, k, v = (rnd(x) for x in (q, k, v))
+    dq, dk, dv = (t.to(dtype).cuda() for t in (q, k, v))
+    for inject in (False, True):
+        refs = attn_ref(q, k, v, h, d ** -0.5, inject)
+        for no_split in (True, False):
+            out = ops.ext_attn(dq, dk, dv, h, d ** -0.5, inject, fused=False, no_split=no_split)
+            assert torch.isfinite(out.float()).all()
+            assert_attn_close(out, refs, f"d64 shift paths K{K} S{S} {dtype} gain={gain} inject={inject} no_split={no_split}",
+                              dtype=dtype)
+
+
+@pytest.mark.parametrize("gain", [3.0, 12.0])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("d", [40, 80])
 def test_ext_attn_folded_shift_paths(d, dtype, gain):
     """The Dh = 40 kernels (fp32 scaling = default, and the opt-in folded scale; Dh = 80 is the plain online softmax,

@@ -1657,6 +1657,11 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
             alpha = sm_decide(std::integral_constant<int, X>{}, move);
             const float mc = m_run * c;
             mc2 = f32x2{mc, mc};
+            // the matrix-pipe denominator holds sums at the OLD shift only (every earlier half tile, the other half of this tile
+            // included) and takes this phase's P -- at the NEW shift -- as the phase goes: rescale it NOW, before the first of
+            // them is added.  (O is rescaled at the END of the phase: its P.V of this phase still multiplies P at the old shift.)
+            if constexpr (LSUM_MFMA)
+                if (move) lacc *= alpha;
         }
         vec8 fr[NM];
 #pragma unroll
@@ -1687,8 +1692,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
             // shift is multiplied in / added
             if (move) {
                 rescale(alpha);
-                if constexpr (LSUM_MFMA) lacc *= alpha;
-                else if constexpr (!ONES) l_run *= alpha;
+                if constexpr (!ONES && !LSUM_MFMA) l_run *= alpha;
             }
             if constexpr (!ONES && !LSUM_MFMA) l_run += lsum;
         }
