@@ -244,6 +244,36 @@ def test_nn_search_lds_dma_kernel(n, S, D, ids, flavour, dtype):
     assert bad == 0 and diff <= 1e-3 * total
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_nn_search_two_target_tile_kernel_ragged(dtype):
+    """A D = 320 search that takes `nn_search_rbg_kernel<.., 2>` (round 6: two 32-target tiles per wave, >= 1024 workgroups of
+    256 targets, >= 24 pivot tiles per workgroup) with a RAGGED last target panel (65 856 = 257.25 panels) and a pivot range
+    split over two workgroups (49 tiles -> 25 + 24): every row of the last two panels and 2 048 sampled rows against the fp32
+    oracle, tie-aware; exact-duplicate pivots: the first index wins; and bit-identical to the one-tile kernel
+    (TF_NN_RB2_MIN_WGS is read once per process, so the comparison is against the per-frame calls, which are too small
+    for the two-tile kernel)."""
+    ops = _ops()
+    n, S, D, ids = 42, 1568, 320, [1, 0]
+    g = torch.Generator(device="cuda").manual_seed(4242)
+    ln = torch.nn.functional.layer_norm
+    piv = ln(torch.randn(2, S, D, generator=g, device="cuda"), (D,)).to(dtype)
+    tgt = ln(torch.randn(n * S, D, generator=g, device="cuda"), (D,)).to(dtype)
+    piv[:, S - 9] = piv[:, 11]
+    tgt[-64:] = piv[1, 11].float().to(dtype)            # in the ragged last panel
+    inv = ops.pivot_inv_norm(piv)
+    idx = ops.nn_search(tgt, piv, inv, ids).cpu()
+    assert bool((idx[0][-64:] == 11).all())
+    rows = torch.cat([torch.arange(n * S - 512, n * S),
+                      torch.randint(0, n * S, (2048,), generator=torch.Generator().manual_seed(3))])
+    total, diff, bad = _iid_rates(idx, tgt, piv, ids, rows)
+    print(f"two-tile kernel, ragged, {str(dtype)[6:]}: {total} pairs, index differs on {diff}, beyond tie {bad}")
+    assert bad == 0 and diff <= 1e-3 * total
+    # one frame at a time: 1 568 targets -> 7 panels, far below the two-tile kernel's grid: the one-tile kernel
+    for f in (0, 17, n - 1):
+        one = ops.nn_search(tgt[f * S:(f + 1) * S], piv, inv, ids).cpu()
+        assert torch.equal(one, idx[:, f * S:(f + 1) * S])
+
+
 @pytest.mark.parametrize("P", [1, 2])
 def test_gather_blend_cfg2_level0_bit_exact(P):
     ops = _ops()
