@@ -1296,7 +1296,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     // ext_attn_kernel's PACK form, so the only differences to the single-bank kernel are the number of staged V^T rows
     // (VR), the number of P.V M-tiles (MT) and the epilogue's row -> (bank, feature) decode.
     constexpr bool PACK = MODE == MODE_DUAL;
-    static_assert(!PACK || DH == 40 || DH == 64, "the packed dual-V image: Dh = 40 (3 M-tiles, ones row 80) or Dh = 64 (4 full M-tiles)");
+    static_assert(!PACK || DH == 40 || DH == 64 || DH == 80,
+                  "the packed dual-V image: Dh = 40 (3 M-tiles, ones row 80), Dh = 64 (4 full M-tiles) or Dh = 80 (5 full M-tiles)");
     constexpr int VR = PACK ? 2 * DH : DH;              // staged V^T rows per tile
     constexpr int MT = PACK ? (2 * DH + 31) / 32 : C::MT;   // P.V M-tiles
     static_assert(DMA != 1 || (!PACK && (64 * DH * 2) % 1024 == 0 && (VR * 128) % 1024 == 0), "dense DMA form: whole 1 KB pieces");
@@ -2078,7 +2079,12 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
 #endif
         return compose([&] { return il ? launch_il<T, DH, TF_TUNE_IL80_NW, MODE_ALL, TF_TUNE_IL80_MINW, TF_TUNE_IL80_DMA>(p, st)
                                        : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st); },
-                       [&] { return launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st); },
+                       [&] {
+#ifdef TF_TUNE_IL80_DUAL
+                                // A/B switch: q/k injection in the interleaved kernel (5-M-tile dual-V image, 2 workgroups of 4 waves per CU)
+                                if (il) return launch_il<T, DH, 4, MODE_DUAL, 2, 2>(p, st);
+#endif
+                                return launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st); },
                        [&] { return il ? launch_il<T, DH, TF_TUNE_IL80_NW, MODE_SOURCE, TF_TUNE_IL80_MINW, TF_TUNE_IL80_DMA>(p, st)
                                        : launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st); });
     } else {

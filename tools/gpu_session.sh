@@ -69,6 +69,9 @@ for stage in "$@"; do
                 for e in "TF_NN_RB2_MIN_WGS=100000000" "TF_NN_RB2_MIN_WGS=2048" "TF_NN_RB2_MIN_WGS=1024" "TF_NN_RB2_MIN_WGS=512" "TF_NN_RB2_MIN_WGS=100000000" "TF_NN_RB2_MIN_WGS=1024"; do echo "== $e" | tee -a $O/nn_rb2_threshold.txt
                   env $e timeout 300 python tools/nn_microbench.py 8,5,4096,320 10,8,9216,320 25,8,4096,320 2>/dev/null | tee -a $O/nn_rb2_threshold.txt
                   env $e timeout 300 python tools/prop_microbench.py 8,5,4096,320 2>/dev/null | grep "per-chunk" | tee -a $O/nn_rb2_threshold.txt; done ;;
+    dual80ab)   for lib in "" il80dual "" il80dual; do echo "== lib=${lib:-default}" | tee -a $O/attn_d80_dual_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 8,1024,8,80 10,576,20,64 2>/dev/null | grep "inject=1" | tee -a $O/attn_d80_dual_ab.txt; done
+                TOKENFLOW_HIP_LIB=build/variants/lib_il80dual.so timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_baseline_configs_gpu.py tests/test_fullsize_gpu.py -q --tb=short -p no:cacheprovider -k "attn or cfg2" 2>&1 | tail -4 | tee -a $O/attn_d80_dual_ab.txt ;;
     seam2)      timeout 900 python -m pytest tests/test_driver_seam.py tests/test_sharded_gpu.py -m gpu -q --tb=short -p no:cacheprovider -s -k "driver or shard_vs_default" 2>&1 | grep -v "^$" | tail -60 > $O/seam2_tests.txt; grep -ai "driver seam\|passed\|failed\|Error\|assert" $O/seam2_tests.txt | cut -c1-300 ;;
     inputsab)   for n in 1 0 1 0; do timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-yardstick --no-parity --input-sets $n > $O/bench_sets_$n.json 2>> $O/inputsab.err; python -c "import json;d=json.load(open('$O/bench_sets_$n.json'));print('input sets',d['input_sets']['n'],d['ms_per_step'],d['ms_per_step_inject_on'],d['ms_per_step_inject_off'],d['roofline']['avg_launch_ms'])" | tee -a $O/input_sets_ab.txt; done ;;
     src4ab)     for lib in "" nosrc4 "" nosrc4; do echo "== lib=${lib:-current}" | tee -a $O/rank_step_src4_ab.txt
