@@ -2080,8 +2080,10 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
         return compose([&] { return il ? launch_il<T, DH, TF_TUNE_IL80_NW, MODE_ALL, TF_TUNE_IL80_MINW, TF_TUNE_IL80_DMA>(p, st)
                                        : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st); },
                        [&] {
-#ifdef TF_TUNE_IL80_DUAL
-                                // A/B switch: q/k injection in the interleaved kernel (5-M-tile dual-V image, 2 workgroups of 4 waves per CU)
+#ifndef TF_TUNE_NO_IL80_DUAL
+                                // Round 6: q/k injection in the interleaved kernel at d = 80 too -- both V banks in one 5-M-tile image
+                                // (uncond rows 0-79, cond 80-159), 184 VGPRs, 2 workgroups of 4 waves per CU: 0.332-0.344 against
+                                // 0.374 ms at cfg2 level 1 on one box (profiles/r06_attn_d80_dual_ab.txt)
                                 if (il) return launch_il<T, DH, 4, MODE_DUAL, 2, 2>(p, st);
 #endif
                                 return launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st); },
