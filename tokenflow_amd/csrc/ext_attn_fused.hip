@@ -22,6 +22,7 @@
 // Arithmetic of a (query, head) depends on KW and PREC only -- never on QW or on the grid -- so a rank reproduces the
 // single-GPU result bit for bit whenever both take this kernel with the same KW (tf_attn_fused_plan: shape-only rules
 // in TF_ATTN_NO_SPLIT mode).
+#include <cstdlib>
 #include <type_traits>
 
 #include "attn_fused.h"
@@ -703,7 +704,9 @@ TfFusedPlan tf_attn_fused_plan(const TfAttnSet* sets, int n_sets, int S, int Dh,
         pl.kw = small_grid ? 4 : 1;
         pl.qw = small_grid ? 1 : 4;
     } else {
-        pl.use = S <= 1024 && small_grid;
+        // TOKENFLOW_FUSED_MAX_S (experiments): frames above it keep the streaming kernels on small grids too
+        static const int max_s = [] { const char* e = getenv("TOKENFLOW_FUSED_MAX_S"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+        pl.use = S <= max_s && small_grid;
         pl.kw = 4;
         pl.qw = 1;
     }

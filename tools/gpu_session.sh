@@ -117,6 +117,12 @@ for stage in "$@"; do
                 for lib in "" build/variants/lib_prev.so; do echo "--- lib: ${lib:-current}" | tee -a $O/ab_prev.txt
                   TOKENFLOW_HIP_LIB=$lib timeout 300 python tools/nn_microbench.py 8,5,256,1280 8,5,64,1280 4,4,64,1280 4,4,16,1280 2>/dev/null | tee -a $O/ab_prev.txt
                   TOKENFLOW_HIP_LIB=$lib timeout 300 python tools/fused_microbench.py --only "L1" --reps 10 2>/dev/null | cut -c1-330 | tee -a $O/ab_prev.txt; done ;;
+    l1streamab) # round 6: a rank's level-1 pivotal pass in the streaming form (round-6 d = 80 kernels) against the fused launch
+                for e in "X=0" "TOKENFLOW_FUSED_MAX_S=256" "X=0" "TOKENFLOW_FUSED_MAX_S=256"; do echo "== $e (X=0: fused launch at level 1)" | tee -a $O/rank_l1_stream_ab.txt
+                  env $e timeout 600 python tools/rank_step_microbench.py --native --only split,auto --no-copies --reps 12 2>/dev/null | grep "step inject\|level 1" | tee -a $O/rank_l1_stream_ab.txt; done ;;
+    il80w8ab)   # round 6: d = 80 plain kernel as 8-wave workgroups forced to 128 VGPRs (4 waves per SIMD, 19 spilled registers) against 4-wave / 145
+                for lib in "" il80w8 "" il80w8; do echo "== lib=${lib:-default}" | tee -a $O/attn_d80_w8_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 8,1024,8,80 8,4096,8,80 4,256,8,80 2>/dev/null | grep "inject=0" | tee -a $O/attn_d80_w8_ab.txt; done ;;
     fusedbench) timeout 600 python tools/fused_microbench.py > $O/fused_microbench.txt 2>&1; tail -40 $O/fused_microbench.txt ;;
     rankstep)   timeout 600 python tools/rank_step_microbench.py --native --only split,auto > $O/rank_step_native.txt 2>&1; tail -14 $O/rank_step_native.txt
                 timeout 300 python tools/rank_step_microbench.py --native --only split,auto --no-copies --no-levels > $O/rank_step_native_nocopies.txt 2>&1; tail -3 $O/rank_step_native_nocopies.txt
