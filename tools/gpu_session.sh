@@ -123,6 +123,12 @@ for stage in "$@"; do
     il80w8ab)   # round 6: d = 80 plain kernel as 8-wave workgroups forced to 128 VGPRs (4 waves per SIMD, 19 spilled registers) against 4-wave / 145
                 for lib in "" il80w8 "" il80w8; do echo "== lib=${lib:-default}" | tee -a $O/attn_d80_w8_ab.txt
                   TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 8,1024,8,80 8,4096,8,80 4,256,8,80 2>/dev/null | grep "inject=0" | tee -a $O/attn_d80_w8_ab.txt; done ;;
+    pmc80)      # instruction-level accounting of the d = 80 interleaved kernel: cfg2 level 1 and the same kernel on a level-0-sized grid
+                for shape in 8,1024,8,80 8,4096,8,80; do
+                for grp in "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES" "SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_THREAD_CYCLES_VALU" "SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32" "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_IFETCH" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VALU_INT32" "SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VALU2 SQ_BUSY_CU_CYCLES SQ_WAVES"; do
+                  rm -rf /tmp/p80; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/p80 -- python $GRAFT_REPO_ROOT/tools/attn_microbench.py $shape > /dev/null 2>>$GRAFT_REPO_ROOT/$O/pmc80.err )
+                  DB=$(find /tmp/p80 -name "*_results.db" | head -1); [ -n "$DB" ] && python tools/rocpd_pmc.py $DB | grep "il_kernel<BF16; 80; 4; 0\|^kernel" >> $O/pmc_d80_S$(echo $shape | cut -d, -f2).csv; done
+                python tools/l0_accounting.py $O/pmc_d80_S$(echo $shape | cut -d, -f2).csv | tee $O/d80_accounting_S$(echo $shape | cut -d, -f2).txt; done ;;
     fusedbench) timeout 600 python tools/fused_microbench.py > $O/fused_microbench.txt 2>&1; tail -40 $O/fused_microbench.txt ;;
     rankstep)   timeout 600 python tools/rank_step_microbench.py --native --only split,auto > $O/rank_step_native.txt 2>&1; tail -14 $O/rank_step_native.txt
                 timeout 300 python tools/rank_step_microbench.py --native --only split,auto --no-copies --no-levels > $O/rank_step_native_nocopies.txt 2>&1; tail -3 $O/rank_step_native_nocopies.txt
