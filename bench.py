@@ -39,9 +39,9 @@ Prints ONE JSON line (rank 0):
                 index-diff rates of a chunk for BOTH target flavours of SURVEY 8(d): video-like and iid (`*_iid`).
   input_sets    step i runs on input set i % n; set s, block b is seeded 1234 + 16 s + b; all sets are
                 generated before the timed region (up to 8, at most 64 GB).
-  roofline_other  NN search (MFMA roof) and gather/blend (HBM roof) on one level-0 chunk, HIP events, after the timed
-                region (rank 0, N = 1); since round 6 also ONE level-0 attention launch of BASELINE configs 4 and 5 (head
-                dim 64) against the MFMA roof.
+  roofline_other  the level-1 attention call (head dim 80 at cfg2), plain and with q/k injection, NN search (MFMA roof) and
+                gather/blend (HBM roof) on one level-0 chunk, HIP events, after the timed region (rank 0, N = 1); since
+                round 6 also ONE level-0 attention launch of BASELINE configs 4 and 5 (head dim 64) against the MFMA roof.
   other_configs   ms per step of BASELINE config 1's geometry (3 eager steps after the timed region, rank 0, N = 1).
   value_bit_identical / value_split   N > 1: frames/s of each timed form, whatever `value` picked (`value_form`).
   yardstick     same box, same run, after the timed region (rank 0, N = 1): what the vendor libraries reach -- hipBLASLt
@@ -255,7 +255,20 @@ def other_rooflines(cfg, blocks, w):
     t_all = timed(lambda: ops.propagate_chunks(blk.tgt, blk.pivots, inv, kf_out, w, n, K, 0, True, blk.res,
                                                torch.float32), reps=10)
     fl_all = workload.nn_flops(n, S, D, 2) * (K - 0.5)
-    return [
+    # the level-1 attention launches (cfg2: head dim 80), plain and with q/k injection: the other streaming kernel of the step
+    lvl1 = []
+    blk1 = next((b for b in blocks if b.lvl == 1), None)
+    if blk1 is not None:
+        d1 = blk1.D // blk1.h
+        for inj in (False, True):
+            t1 = timed(lambda: ops.ext_attn(blk1.q, blk1.k, blk1.v, blk1.h, d1 ** -0.5, inj))
+            lvl1.append({"kernel": "tf_ext_attn_fwd, level 1 (S = %d, %d heads of %d), %s, one call (+ V^T pre-pass%s)"
+                                   % (blk1.S, blk1.h, d1, "q/k injection on" if inj else "no q/k injection",
+                                      " + source launch; algorithmic flops, the call executes fewer" if inj else ""),
+                         "bound": "mfma", "achieved": round(blk1.attn_flops / t1 / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": round(blk1.attn_flops / t1 / 1e9 / 2500.0, 4), "avg_launch_ms": round(t1, 4),
+                         "algorithmic_gflop_per_launch": round(blk1.attn_flops / 1e9, 1)})
+    return lvl1 + [
         {"kernel": "tf_nn_gather_blend_chunks (level 0, all %d chunks of a block: the launch pair the step issues -- "
                    "batched NN search + gather/blend/residual; flops = the searches', time = both launches)" % K,
          "bound": "mfma", "achieved": round(fl_all / t_all / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
