@@ -777,6 +777,10 @@ static int split_plan(int K, int Kq, int S, int H, int Dh, bool inject, int part
     if (K * tpf < 16) return 1;   // a bank of a few tiles: the merge launch costs more than it buys (8x8 level)
     int nseg = 1;
     while (wgs * 4 * nseg < (int64_t)occ * 1024 && nseg * 2 <= K && (K / (nseg * 2)) * tpf >= 2) nseg *= 2;
+    // A SHORT bank (<= 8192 keys) that already has half the waves the kernel can hold gains less from the second half than the
+    // partial results + merge launch cost: BASELINE config 1, level 0 (K = 4, S = 1024, 2 of 4 waves per SIMD): 0.091 against
+    // 0.098 ms unsplit (round 6, one box, TOKENFLOW_ATTN_NSEG A/B); the dual-V launch keeps its split (0.092 against 0.111)
+    if (!dual && nseg == 2 && (int64_t)K * S <= 8192) nseg = 1;
     // TOKENFLOW_ATTN_NSEG=n (experiments): force n runs
     static const int forced = [] { const char* e = getenv("TOKENFLOW_ATTN_NSEG"); return e ? atoi(e) : 0; }();
     if (forced > 0) return forced <= K ? forced : K;
