@@ -473,9 +473,9 @@ def test_loopback_wire_model_holds_the_stream():
 
     comm = HipComm.loopback(3, 8, wire=(2000.0, 0.008))    # 2 ms latency + 8 KB on a link at 8 MB/s = 1 ms more
     t_wire = timed(comm)
-    assert 2900.0 <= t_wire <= 4500.0, t_wire
+    assert 2900.0 <= t_wire <= 10000.0, t_wire      # the hold is a LOWER bound; the upper one only catches a runaway
     _lib.check(_lib.load().tf_comm_loopback_wire(comm._h, 0.0, 0.0), "tf_comm_loopback_wire")
-    assert timed(comm) < 500.0
+    assert timed(comm) < 2000.0
     # neighbour exchange: one link out, one link in -> max(sent, received) bytes
     _lib.check(_lib.load().tf_comm_loopback_wire(comm._h, 1000.0, 0.0), "tf_comm_loopback_wire")
     got = [torch.zeros(4096, device="cuda", dtype=torch.bfloat16)]
@@ -484,7 +484,7 @@ def test_loopback_wire_model_holds_the_stream():
     comm.sendrecv([send[0]], 4, got, 2)
     e1.record()
     torch.cuda.synchronize()
-    assert torch.equal(got[0], send[0]) and 900.0 <= e0.elapsed_time(e1) * 1e3 <= 2500.0
+    assert torch.equal(got[0], send[0]) and 900.0 <= e0.elapsed_time(e1) * 1e3 <= 8000.0
     comm.close()
     plain = HipComm.loopback(0, 1)
     plain.close()
