@@ -225,7 +225,8 @@ def test_ext_attn_d64_score_bound_shift_paths(K, S, h, d, dtype, gain):
     per-tile maximum while |q| max|k| c - shift stays under its threshold; planted keys aligned with their queries make
     the scores climb (gain 3: inside the bf16 headroom, no rescale after the first tile; gain 12, and f16 at either
     gain: the bound fails, every half tile looks at its maximum and the deferred shift moves in late tiles -- O AND the
-    matrix-pipe denominator are rescaled).  Plain and q/k-injected (the 4-M-tile dual-V image), one-pass and split."""
+    matrix-pipe denominator are rescaled).  Plain and q/k-injected (the dual-V images of the interleaved kernel: 3 M-tiles at
+    d = 40, 4 at d = 64, 5 at d = 80 -- the last one since the end of round 6), one-pass and split."""
     ops = _ops()
     g = torch.Generator().manual_seed(29 + S + d)
     q, k, v = (torch.randn(3 * K, S, h * d, generator=g) for _ in range(3))
