@@ -5,7 +5,11 @@
 // shape buy clock?  (tools/ubench/mfma_shapes rand: bare MFMAs run 2.21 vs 1.89 PFLOP/s.)
 //   SHAPE 0: S^T = K Q^T as 2 x 3 MFMAs 32x32x16 (K = 48), O^T += V^T P as 2 x 4 (M = 64)          -> 14 x 32 cycles
 //   SHAPE 1: S^T as 4 x 2 x 2 MFMAs 16x16x32 (K = 64), O^T as 3 x 2 x 2 (M = 48)                    -> 28 x 16 cycles
-// Both read 14 fragments of 1 KiB from LDS per tile and run the same softmax mix (16 pk_fma, 32 exp2, 16 cvt_pk).
+//   SHAPE 2 (round 6): MIXED -- S^T as in SHAPE 0 (2 x 3 MFMAs 32x32x16, K = 48), P re-laid out from the 32x32 accumulator layout
+//            (lane = query, 16 keys) to the 16x16x32 B layout (lane = query % 16, 8 keys) by ONE v_permlane16_swap per register
+//            pair (8 per tile), O^T += V^T P as 3 x 2 x 2 MFMAs 16x16x32 (M = 48)          -> 6 x 32 + 12 x 16 = 384 cycles (-14 %),
+//            12 fragments per tile instead of 14, +4 MFMA issues and +8 permlane issues on the VALU port
+// SHAPE 0 / 1 read 14 fragments of 1 KiB from LDS per tile; all run the same softmax mix (16 pk_fma, 32 exp2, 16 cvt_pk).
 // No global loads, LDS writes or barriers in the loop.
 //   hipcc --offload-arch=gfx950 -O3 -o attn_tile_proxy attn_tile_proxy.hip && ./attn_tile_proxy
 #include <hip/hip_runtime.h>
@@ -29,7 +33,7 @@ __global__ __launch_bounds__(512) void k(const u32x4* __restrict__ src, float* o
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < 2 * 16 * 64; i += 512) lds[i] = src[i];
     __syncthreads();
-    const float c = 0.11f, m = 8.f;
+    const float c = 0.11f, m = 8.f, m_ = 8.f;
     bf16x8 q[4];
     for (int t = 0; t < 4; ++t) q[t] = __builtin_bit_cast(bf16x8, src[(t * 64 + lane + tid) & 2047]);
     if (SHAPE == 0) {
@@ -70,6 +74,56 @@ __global__ __launch_bounds__(512) void k(const u32x4* __restrict__ src, float* o
         float s = 0.f;
         for (int r = 0; r < 16; ++r) s += o0[r] + o1[r];
         out[blockIdx.x * 512 + tid] = s;
+    } else if (SHAPE == 2) {
+        f32x4 o[3][2];
+        for (int d = 0; d < 3; ++d)
+            for (int t = 0; t < 2; ++t) o[d][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) {
+            int off = (it & 1) * 1024 + lane;
+            asm volatile("" : "+v"(off));
+            const u32x4* f = lds + off;
+            f32x16 s0, s1;
+            for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[(2 * t) * 64]), q[t], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[(2 * t + 1) * 64]), q[t], s1, 0, 0, 0);
+            }
+            // P of key half h: registers 0-3 = accumulator rows j = 0, 1 (8 keys), 4-7 = rows j = 2, 3
+            unsigned w[2][8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const f32x16& sv = h == 0 ? s0 : s1;
+                    const f32x2 x = f32x2{sv[2 * m], sv[2 * m + 1]} * c - m_;
+                    w[h][m] = pack2(__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1]));
+                }
+            // one v_permlane16_swap per register pair: odd 16-lane rows of the first <-> even rows of the second
+            u32x4 pt[2][2];   // [key half][16-query N-tile]: the 16x16x32 B operand (8 keys per lane)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const auto r = __builtin_amdgcn_permlane16_swap(w[h][i], w[h][4 + i], false, false);
+                    pt[h][0][i] = r[0];
+                    pt[h][1][i] = r[1];
+                }
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bf16x8 v = __builtin_bit_cast(bf16x8, f[(6 + 2 * d + h) * 64]);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        o[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v, __builtin_bit_cast(bf16x8, pt[h][t]), o[d][t], 0, 0, 0);
+                }
+        }
+        float sm = 0.f;
+        for (int d = 0; d < 3; ++d)
+            for (int t = 0; t < 2; ++t)
+                for (int r = 0; r < 4; ++r) sm += o[d][t][r];
+        out[blockIdx.x * 512 + tid] = sm;
     } else {
         f32x4 o[3][2];
         for (int d = 0; d < 3; ++d)
@@ -150,11 +204,12 @@ int main(int argc, char** argv) {
     (void)hipMemcpy(src, h, 2048 * 16, hipMemcpyHostToDevice);
     (void)hipMalloc(&out, 512 * 512 * 4);
     for (int rep = 0; rep < 2; ++rep) {
-        const float t0 = run<0>(src, out, iters), t1 = run<1>(src, out, iters);
+        const float t0 = run<0>(src, out, iters), t1 = run<1>(src, out, iters), t2 = run<2>(src, out, iters);
         const double tiles = (double)iters * 512 * 8;                 // wave-tiles
         const double fl = tiles * 2.0 * 2 * 32 * 64 * 40;             // algorithmic flops at head dim 40
-        printf("4 waves/SIMD, %d tiles per wave: 32x32x16 %.1f ms = %.0f TF/s (algorithmic) | 16x16x32 %.1f ms = %.0f TF/s\n",
-               iters, t0, fl / t0 / 1e9, t1, fl / t1 / 1e9);
+        printf("4 waves/SIMD, %d tiles per wave: 32x32x16 %.1f ms = %.0f TF/s (algorithmic) | 16x16x32 %.1f ms = %.0f TF/s | "
+               "mixed (QK^T 32x32x16, P.V 16x16x32 + permlane16_swap) %.1f ms = %.0f TF/s\n",
+               iters, t0, fl / t0 / 1e9, t1, fl / t1 / 1e9, t2, fl / t2 / 1e9);
     }
     return 0;
 }
