@@ -1275,6 +1275,39 @@ struct IlSchedule {   // MFMA order of one phase: QK^T k-steps (one accumulator 
     }
 };
 
+// MIXED MFMA shapes (Dh = 40, one bank, round 6; off: TF_TUNE_NO_IL40_MIX): QK^T stays 32x32x16 (K = 48), P.V runs as 16x16x32 MFMAs over
+// THREE 16-row M-tiles (rows 0-47 of the same V^T image: 40 features, the ones row, 7 zero rows) and the two 16-query halves
+// of the wave's tile: 6 short MFMAs (16 clocks each) per 32-key half instead of 4 long ones -- 192 instead of 224 matrix-pipe
+// clocks per phase.  A step's fragment is read once per M-tile (fidx: the step whose LDS fragment this step multiplies).
+template <int KS, bool NEXT>
+struct IlScheduleMix {
+    static constexpr int N = (NEXT ? KS : 0) + 6;
+    int is_pv[N] = {}, a[N] = {}, b[N] = {}, fidx[N] = {};   // P.V: a = M-tile, b = 16-query half; QK^T: a = k-step
+    constexpr IlScheduleMix() {
+        int i = 0;
+        if (NEXT) {
+            // QK0 PV00 PV01 | QK1 PV10 PV11 | QK2 PV20 PV21: the QK^T chain's links lie two short MFMAs (32 clocks) apart
+            for (int d = 0; d < 3; ++d) {
+                if (d < KS) {
+                    is_pv[i] = 0, a[i] = d, fidx[i] = i;
+                    ++i;
+                }
+                is_pv[i] = 1, a[i] = d, b[i] = 0, fidx[i] = i;
+                is_pv[i + 1] = 1, a[i + 1] = d, b[i + 1] = 1, fidx[i + 1] = i;
+                i += 2;
+            }
+            for (int t = 3; t < KS; ++t) {
+                is_pv[i] = 0, a[i] = t, fidx[i] = i;
+                ++i;
+            }
+        } else {
+            // PV00 PV10 PV01 PV11 PV20 PV21: the first two steps own their fragments (cross-phase prefetch hands over two)
+            const int dd[6] = {0, 1, 0, 1, 2, 2}, tt[6] = {0, 0, 1, 1, 0, 1}, ff[6] = {0, 1, 0, 1, 4, 4};
+            for (i = 0; i < 6; ++i) is_pv[i] = 1, a[i] = dd[i], b[i] = tt[i], fidx[i] = ff[i];
+        }
+    }
+};
+
 // DMA != 0 (non-PACK forms): K and V^T tiles go global -> LDS by `global_load_lds_dwordx4` instead of through registers: no
 // staging VGPRs, no ds_write pass.  The DMA writes lane-linearly (wave-uniform LDS base + lane * 16 B per instruction, a
 // "piece" of 1 KB), the per-lane SOURCE address is free, so any LDS image whose 16-B slots are filled piece by piece works:
@@ -1300,6 +1333,11 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     // ext_attn_kernel's PACK form, so the only differences to the single-bank kernel are the number of staged V^T rows
     // (VR), the number of P.V M-tiles (MT) and the epilogue's row -> (bank, feature) decode.
     constexpr bool PACK = MODE == MODE_DUAL;
+#ifndef TF_TUNE_NO_IL40_MIX
+    constexpr bool MIX = DH == 40 && !PACK && DMA == 2;   // mixed MFMA shapes, see IlScheduleMix
+#else
+    constexpr bool MIX = false;
+#endif
     static_assert(!PACK || DH == 40 || DH == 64 || DH == 80,
                   "the packed dual-V image: Dh = 40 (3 M-tiles, ones row 80), Dh = 64 (4 full M-tiles) or Dh = 80 (5 full M-tiles)");
     constexpr int VR = PACK ? 2 * DH : DH;              // staged V^T rows per tile
@@ -1514,7 +1552,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
     f32x16 o[MT], s[2];
-    vec8 pf[2][2];      // P of the two 32-key halves, two 16-key k-steps each
+    f32x4 o16[3][2];    // MIX: O^T as [16-row M-tile][16-query half]: lane l = query l & 15 of the half, rows 4 (l >> 4) + i
+    vec8 pf[2][2];      // P of the two 32-key halves, two 16-key k-steps each (MIX: after p_relayout, the two 16-query halves)
     float m_run = -INFINITY;   // BOUND: deferred shift; else the lagged running maximum (raw-score units)
     const float lag = TF_ATTN_LAG / c;   // raw-score units
     float l_run = 0.f;         // !ONES: this lane's share of the denominator
@@ -1537,11 +1576,33 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[mt][r] = 0.f;
 #pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) o16[d][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int j = 0; j < 8; ++j) pf[kt][ks][j] = (E)0.f;
+    // MIX: P of half X from the 32x32 accumulator layout (lane = query l & 31; pf[X][0] = accumulator registers 0-7, pf[X][1] =
+    // 8-15) to the 16x16x32 B layout (lane = query l & 15 of a 16-query half, 8 keys per 16-lane row).  v_permlane16_swap
+    // exchanges the odd 16-lane rows of its first operand with the even rows of its second: afterwards pf[X][0] holds, in
+    // rows 0 / 1 / 2 / 3, registers 0-7 | 8-15 of lane half 0 and 0-7 | 8-15 of lane half 1 of queries 0-15, pf[X][1] the same of
+    // queries 16-31 -- the k order (row g: accumulator registers 8 (g & 1) .. +7 of lane half g >> 1) is the one the V^T
+    // fragment read of the mixed form uses.
+    auto p_relayout = [&](auto x_c) {
+        constexpr int X = decltype(x_c)::value;
+        u32x4 a = __builtin_bit_cast(u32x4, pf[X][0]), b2 = __builtin_bit_cast(u32x4, pf[X][1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const auto r = __builtin_amdgcn_permlane16_swap(a[i], b2[i], false, false);
+            a[i] = r[0];
+            b2[i] = r[1];
+        }
+        pf[X][0] = __builtin_bit_cast(vec8, a);
+        pf[X][1] = __builtin_bit_cast(vec8, b2);
+    };
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // decision part of the online softmax of half X: returns alpha (1 = no move) and leaves m_run updated
@@ -1582,6 +1643,17 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
         return alpha;
     };
     auto rescale = [&](float alpha) {
+        if constexpr (MIX) {
+            // alpha belongs to query l & 31; O^T holds queries l & 15 (half 0) and 16 + (l & 15) (half 1): one row swap delivers both
+            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(alpha), __float_as_uint(alpha), false, false);
+            const float a0 = __uint_as_float(r[0]), a1 = __uint_as_float(r[1]);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                o16[d][0] *= a0;
+                o16[d][1] *= a1;
+            }
+            return;
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -1628,6 +1700,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     // LDS fragment i of the MFMA sequence of phase (Hh, NEXT): a P.V fragment of V^T buffer vbuf or a QK^T fragment of K buffer kbuf
     auto frag = [&](auto h_c, auto next_c, int i, int vbuf, int kbuf) -> vec8 {
         constexpr int Hh = decltype(h_c)::value;
+        if constexpr (MIX) {
+            constexpr IlScheduleMix<C::KS, decltype(next_c)::value> schm{};
+            if (schm.is_pv[i])   // 16 rows x 32 keys of M-tile a: lane row g reads the image columns of k-step g & 1, lane half g >> 1
+                return __builtin_bit_cast(vec8, ld16(sV(vbuf) + (schm.a[i] * 16 + (lane & 15)) * VROW + Hh * 32 +
+                                                     16 * ((lane >> 4) & 1) + 8 * hi));
+            return __builtin_bit_cast(vec8, ld16(sK(kbuf) + (Hh * 32 + l31) * KROW + 8 * hi + 16 * schm.a[i]));
+        }
         constexpr IlSchedule<MT, C::KS, decltype(next_c)::value> sch{};
         if (sch.is_pv[i]) {
             const E* vbase = sV(vbuf) + l31 * VROW + (DMA == 1 ? 0 : Hh * 32 + 8 * hi);
@@ -1652,7 +1731,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
         constexpr bool NEXT = decltype(next_c)::value, SM = decltype(sm_c)::value;
         constexpr bool PRE_IN = XPF && decltype(pre_in_c)::value;     // fragments 0 .. PF-1 arrive in fr_carry
         constexpr bool PRE_OUT = XPF && decltype(pre_out_c)::value;   // the following phase (half 1 - Hh, same NEXT, same buffers) gets its first PF
-        constexpr IlSchedule<MT, C::KS, NEXT> sch{};
+        constexpr std::conditional_t<MIX, IlScheduleMix<C::KS, NEXT>, IlSchedule<MT, C::KS, NEXT>> sch{};
         constexpr int NM = sch.N;
         static_assert(PF <= NM, "prefetch distance beyond one phase");
         bool move = false;
@@ -1673,9 +1752,23 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
         for (int i = 0; i < PF; ++i) fr[i] = PRE_IN ? fr_carry[i] : frag(h_c, next_c, i, vbuf, kbuf);
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
-            if (i + PF < NM) fr[i + PF] = frag(h_c, next_c, i + PF, vbuf, kbuf);
-            else if constexpr (PRE_OUT) fr_carry[i + PF - NM] = frag(std::integral_constant<int, X>{}, next_c, i + PF - NM, vbuf, kbuf);
-            if (sch.is_pv[i]) {
+            if constexpr (MIX) {
+                // a step reads its own fragment only (fidx == i); the first PF steps of every mixed schedule own theirs
+                if (i + PF < NM) {
+                    if (sch.fidx[i + PF] == i + PF) fr[i + PF] = frag(h_c, next_c, i + PF, vbuf, kbuf);
+                } else if constexpr (PRE_OUT) {
+                    fr_carry[i + PF - NM] = frag(std::integral_constant<int, X>{}, next_c, i + PF - NM, vbuf, kbuf);
+                }
+            } else {
+                if (i + PF < NM) fr[i + PF] = frag(h_c, next_c, i + PF, vbuf, kbuf);
+                else if constexpr (PRE_OUT) fr_carry[i + PF - NM] = frag(std::integral_constant<int, X>{}, next_c, i + PF - NM, vbuf, kbuf);
+            }
+            if constexpr (MIX) {
+                if (sch.is_pv[i])
+                    o16[sch.a[i]][sch.b[i]] = T::mfma16(fr[sch.fidx[i]], pf[Hh][sch.b[i]], o16[sch.a[i]][sch.b[i]]);
+                else
+                    s[Hh] = T::mfma32(fr[i], qf[sch.a[i]], sch.a[i] == 0 ? zero : s[Hh]);
+            } else if (sch.is_pv[i]) {
                 o[sch.a[i]] = T::mfma32(fr[i], pf[Hh][sch.b[i]], o[sch.a[i]]);
             } else {
                 s[Hh] = T::mfma32(fr[i], qf[sch.a[i]], sch.a[i] == 0 ? zero : s[Hh]);
@@ -1685,12 +1778,25 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
                 for (int un = (i * 8) / NM; un < ((i + 1) * 8) / NM; ++un)
                     sm_unit(std::integral_constant<int, X>{}, un, c2, mc2, lsum);
             }
+            // The non-mixed forms pin every step (1 MFMA : its share of the softmax): without the pins they lose 1-2 % at every head
+            // dim (profiles/r06_attn_d40_mix_ab.txt, nosb rows).  The mixed form is faster when hipcc places the softmax itself
+            // (it moves the six short P.V MFMAs to the front of the phase, beside the multiply-adds, and the exponentials beside the
+            // three long QK^T MFMAs): 3.53 against 3.63 ms pinned, 3.65 the non-mixed kernel.  TF_TUNE_IL40_MIX_PINNED: pinned.
+#ifdef TF_TUNE_IL40_MIX_PINNED
             __builtin_amdgcn_sched_barrier(0);
+#else
+            if constexpr (!MIX) __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         if constexpr (SM) {
             // P of half X must exist HERE (keeps the register-only softmax from sinking towards its consumer)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(pf[X][ks]));
+            if constexpr (MIX) {
+                p_relayout(std::integral_constant<int, X>{});
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(pf[X][ks]));
+            }
             if constexpr (LSUM_MFMA) lacc = T::mfma4(ones4, pf[X][1].hi, lacc);   // the last pair of the half (units 6, 7)
             // the shift moved: O (now including this phase's P.V, computed against the old shift) -- and the part of
             // the denominator accumulated so far, all of it at the old shift -- is rescaled before any P at the new
@@ -1736,6 +1842,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
         float lsum = 0.f;
 #pragma unroll
         for (int un = 0; un < 8; ++un) sm_unit(H0{}, un, c2, mc2, lsum);
+        if constexpr (MIX) p_relayout(H0{});
         if constexpr (LSUM_MFMA) lacc = T::mfma4(ones4, pf[0][1].hi, lacc);
         if constexpr (!ONES && !LSUM_MFMA) l_run = lsum;
     }
@@ -1792,6 +1899,46 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     }
 
     // ---- epilogue
+    if constexpr (MIX) {
+        // O^T[16 d + 4 g + i][16 t + (l & 15)] = o16[d][t][i], g = l >> 4; the ones row (40 = 16 * 2 + 4 * 2 + 0) is register 0 of
+        // M-tile 2 in the lanes of row g = 2
+        const int g = lane >> 4, n16 = lane & 15;
+        float l_t[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) l_t[t] = __shfl(o16[2][t][0], 32 + n16);
+        if (split) {
+            constexpr int PS = DH + 8;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int qr = qt * (32 * NW) + wave * 32 + 16 * t + n16;
+                if (qr < S) {
+                    const int64_t R = (((int64_t)(b - 1) * Kq + f) * H + h) * S + qr;
+                    float* row = p.partials + (R * nseg + seg) * PS;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+                        if (16 * d + 4 * g < DH) *reinterpret_cast<f32x4*>(row + 16 * d + 4 * g) = o16[d][t];
+                    if (g == 2) row[DH] = o16[2][t][0];
+                }
+            }
+            if (hi == 0 && q_ok) {   // the shift is this lane's own query's (l & 31)
+                const int64_t R = (((int64_t)(b - 1) * Kq + f) * H + h) * S + q_row;
+                p.partials[(R * nseg + seg) * PS + DH + 1] = m_run * c;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int qr = qt * (32 * NW) + wave * 32 + 16 * t + n16;
+                if (qr < S) {
+                    const float inv = 1.0f / l_t[t];
+                    const int64_t op = b * p.o_bs + f * p.o_fs + (int64_t)qr * (H * DH) + h * DH;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+                        if (16 * d + 4 * g < DH) store_out4<E, vec4>(p.out, op + 16 * d + 4 * g, o16[d][t] * inv, p.out_f32);
+                }
+            }
+        }
+        return;
+    }
     float l_tot;
     if constexpr (ONES)
         l_tot = __shfl(o[MT - 1][ONES_R], l31);   // row VR of the V^T image is 1.0: sum of P from the MFMA

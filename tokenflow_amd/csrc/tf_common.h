@@ -20,6 +20,11 @@ struct BF16 {
     static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
+    // 16x16x32: A lane l = row l & 15, k = 8 (l >> 4) .. +7; B lane l = column l & 15, same k; C/D lane l = column l & 15,
+    // rows 4 (l >> 4) + i, i = 0..3
+    static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
     // 16 blocks of 4x4x4: lane l = block l / 4, column l % 4 of B and of D.  With A = ones every lane gets the sum of its
     // own 4 B values in all 4 result registers (tools/ubench/mfma4_probe.hip)
     static __device__ __forceinline__ f32x4 mfma4(vec4 a, vec4 b, f32x4 c) {
@@ -33,6 +38,9 @@ struct F16 {
     typedef _Float16 vec4 __attribute__((ext_vector_type(4)));
     static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ f32x4 mfma4(vec4 a, vec4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, c, 0, 0, 0);

@@ -129,6 +129,19 @@ for stage in "$@"; do
                   rm -rf /tmp/p80; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/p80 -- python $GRAFT_REPO_ROOT/tools/attn_microbench.py $shape > /dev/null 2>>$GRAFT_REPO_ROOT/$O/pmc80.err )
                   DB=$(find /tmp/p80 -name "*_results.db" | head -1); [ -n "$DB" ] && python tools/rocpd_pmc.py $DB | grep "il_kernel<BF16; 80; 4; 0\|^kernel" >> $O/pmc_d80_S$(echo $shape | cut -d, -f2).csv; done
                 python tools/l0_accounting.py $O/pmc_d80_S$(echo $shape | cut -d, -f2).csv | tee $O/d80_accounting_S$(echo $shape | cut -d, -f2).txt; done ;;
+    mixab)      # round 6: mixed MFMA shapes in the d = 40 interleaved kernel (TF_TUNE_IL40_MIX: QK^T 32x32x16, P.V 16x16x32 behind v_permlane16_swap)
+                TOKENFLOW_HIP_LIB=build/variants/lib_il40mix.so timeout 900 python -m pytest tests/test_kernels_gpu.py -q --tb=short -p no:cacheprovider -x -k "attn" 2>&1 | tail -12 | tee -a $O/attn_d40_mix_ab.txt
+                for lib in "" il40mix "" il40mix "" il40mix; do echo "== lib=${lib:-default}" | tee -a $O/attn_d40_mix_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 8,4096,8,40 4,1024,8,40 2>/dev/null | tee -a $O/attn_d40_mix_ab.txt; done ;;
+    mixab2)     for lib in "" il40mix il40mix2 il40mix3 "" il40mix il40mix2 il40mix3; do echo "== lib=${lib:-default}" | tee -a $O/attn_d40_mix_ab2.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 8,4096,8,40 2>/dev/null | grep "inject=0" | tee -a $O/attn_d40_mix_ab2.txt; done ;;
+    nosbab)     for lib in "" il40mix2 nosb40 nosb64 nosb80 "" il40mix2 nosb40 nosb64 nosb80; do echo "== lib=${lib:-default}" | tee -a $O/attn_il_nosb_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 8,4096,8,40 10,9216,5,64 8,1024,8,80 2>/dev/null | tee -a $O/attn_il_nosb_ab.txt; done ;;
+    mixab3)     for lib in "" il40mix2 il40mix4 il40mix1o il40mix4o il40mix2o "" il40mix2 il40mix4 il40mix1o il40mix4o il40mix2o; do echo "== lib=${lib:-default}" | tee -a $O/attn_d40_mix_ab3.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 8,4096,8,40 4,1024,8,40 2>/dev/null | grep "inject=0" | tee -a $O/attn_d40_mix_ab3.txt; done ;;
+    mixstep)    # whole-step A/B on ONE box: the d = 40 kernel without the mixed MFMA shapes (build/variants/lib_nomix.so) against the default
+                for lib in nomix "" nomix ""; do TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-yardstick --no-parity --no-other-configs > $O/bench_mix_${lib:-default}.json 2>> $O/mixstep.err
+                  python -c "import json;d=json.load(open('$O/bench_mix_${lib:-default}.json'));print('lib=${lib:-default}', 'step', d['ms_per_step'], 'inject on/off', d['ms_per_step_inject_on'], d['ms_per_step_inject_off'], 'level-0 plain launch', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'])" | tee -a $O/bench_mix_step_ab.txt; done ;;
     fusedbench) timeout 600 python tools/fused_microbench.py > $O/fused_microbench.txt 2>&1; tail -40 $O/fused_microbench.txt ;;
     rankstep)   timeout 600 python tools/rank_step_microbench.py --native --only split,auto > $O/rank_step_native.txt 2>&1; tail -14 $O/rank_step_native.txt
                 timeout 300 python tools/rank_step_microbench.py --native --only split,auto --no-copies --no-levels > $O/rank_step_native_nocopies.txt 2>&1; tail -3 $O/rank_step_native_nocopies.txt
