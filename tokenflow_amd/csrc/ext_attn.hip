@@ -2114,9 +2114,15 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
 #ifndef TF_TUNE_IL40_DMA
 #define TF_TUNE_IL40_DMA 2
 #endif
+#ifndef TF_TUNE_IL40_NW
+#define TF_TUNE_IL40_NW 8
+#endif
+#ifndef TF_TUNE_IL40_MINW
+#define TF_TUNE_IL40_MINW 4
+#endif
 #if TF_TUNE_IL40_DMA != 0
             if (il)
-                return compose([&] { return launch_il<T, 40, 8, MODE_ALL, 4, TF_TUNE_IL40_DMA>(p, st); },
+                return compose([&] { return launch_il<T, 40, TF_TUNE_IL40_NW, MODE_ALL, TF_TUNE_IL40_MINW, TF_TUNE_IL40_DMA>(p, st); },
                                [&] {
 #ifndef TF_TUNE_NO_IL40_DUAL
                                    // Round 6: the packed dual-V kernel with LDS-DMA staging, 8-wave workgroups, FOUR waves per SIMD (128

@@ -142,6 +142,10 @@ for stage in "$@"; do
     mixstep)    # whole-step A/B on ONE box: the d = 40 kernel without the mixed MFMA shapes (build/variants/lib_nomix.so) against the default
                 for lib in nomix "" nomix ""; do TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-yardstick --no-parity --no-other-configs > $O/bench_mix_${lib:-default}.json 2>> $O/mixstep.err
                   python -c "import json;d=json.load(open('$O/bench_mix_${lib:-default}.json'));print('lib=${lib:-default}', 'step', d['ms_per_step'], 'inject on/off', d['ms_per_step_inject_on'], d['ms_per_step_inject_off'], 'level-0 plain launch', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'])" | tee -a $O/bench_mix_step_ab.txt; done ;;
+    mixab4)     for lib in "" mixpf3 mixnoxpf mixpf1 "" mixpf3 mixnoxpf mixpf1; do echo "== lib=${lib:-default}" | tee -a $O/attn_d40_mix_ab4.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 8,4096,8,40 2>/dev/null | grep "inject=0" | tee -a $O/attn_d40_mix_ab4.txt; done ;;
+    mixab5)     for lib in "" mixw4m5 mixw4m4 "" mixw4m5 mixw4m4; do echo "== lib=${lib:-default}" | tee -a $O/attn_d40_mix_ab5.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 8,4096,8,40 2>/dev/null | grep "inject=0" | tee -a $O/attn_d40_mix_ab5.txt; done ;;
     fusedbench) timeout 600 python tools/fused_microbench.py > $O/fused_microbench.txt 2>&1; tail -40 $O/fused_microbench.txt ;;
     rankstep)   timeout 600 python tools/rank_step_microbench.py --native --only split,auto > $O/rank_step_native.txt 2>&1; tail -14 $O/rank_step_native.txt
                 timeout 300 python tools/rank_step_microbench.py --native --only split,auto --no-copies --no-levels > $O/rank_step_native_nocopies.txt 2>&1; tail -3 $O/rank_step_native_nocopies.txt
