@@ -886,7 +886,7 @@ def main():
             traffic_src = tj.get("source")
         except Exception:
             traffic = None
-    kname = {40: "ext_attn_il_kernel<BF16, 40, 8, MODE_ALL, 4, 2> (half-tile interleaved, LDS-DMA staged tiles, mixed MFMA shapes: "
+    kname = {40: "ext_attn_il_kernel<BF16, 40, 8, MODE_ALL, 4, 3> (half-tile interleaved, LDS-DMA staged tiles, mixed MFMA shapes: "
                  "QK^T 32x32x16, P.V 16x16x32)",
              64: "ext_attn_il_kernel<BF16, 64, 8, MODE_ALL, 4, 2> (half-tile interleaved, LDS-DMA staged tiles, score bound)",
              80: "ext_attn_il_kernel<BF16, 80, 4, MODE_ALL, 3, 2> (half-tile interleaved, LDS-DMA staged tiles)"}.get(

@@ -57,6 +57,8 @@ extern "C" {
 #define TF_ATTN_HINT_QB2 (1 << 14)                   /* wave-private form, head dims <= 80: two 32-query blocks per wave */
 #define TF_ATTN_PRECISE_P (1 << 15)                  /* fused kernel, bf16: carry P as hi + lo whatever the size */
 #define TF_ATTN_NO_PRECISE_P (1 << 16)               /* fused kernel: P in one 16-bit value whatever the size */
+#define TF_ATTN_HINT_MIX (1 << 18)                   /* Dh = 40 streaming kernel: the mixed-MFMA-shape form whatever the launch size (it is the
+                                                        default for launches of >= 1024 workgroups outside the bit-stable mode); tests, measurements */
 
 /* argument errors */
 #define TF_ERR_NULL (-1)

@@ -245,6 +245,45 @@ def test_ext_attn_d64_score_bound_shift_paths(K, S, h, d, dtype, gain):
                               dtype=dtype)
 
 
+@pytest.mark.parametrize("gain", [0.0, 3.0, 12.0])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("K,S,h", [(2, 576, 2), (3, 1024, 1), (2, 256, 2), (4, 320, 3)])
+def test_ext_attn_mixed_mfma_shapes(K, S, h, dtype, gain):
+    """The mixed-MFMA-shape form of the d = 40 interleaved kernel (QK^T 32x32x16, P re-laid out by v_permlane16_swap, P.V
+    16x16x32 over three 16-row M-tiles; csrc/ext_attn.hip, IlScheduleMix).  By default only launches of >= 1024 workgroups
+    take it (the full-size tests and bench.py's parity leg); TF_ATTN_HINT_MIX forces it here on small grids: N(0,1) and
+    peaked logits (the deferred shift moves in late tiles: O rescaled through the row swap), plain and q/k-injected (the
+    source launch in the mixed form beside the dual-V kernel), one-pass and split (the partial results' layout), bf16 and
+    f16, against the oracle -- and against the non-mixed kernel within the same bound."""
+    ops = _ops()
+    from tokenflow_amd import _lib
+    d = 40
+    g = torch.Generator().manual_seed(41 + S + K)
+    q, k, v = (torch.randn(3 * K, S, h * d, generator=g) for _ in range(3))
+    if gain:
+        for b in range(3 * K):
+            for s_ in range(0, S, 5):
+                k[b, (s_ * 3 + S - 60) % S] = q[b, s_] * gain
+    rnd = orc.bf16_round if dtype == torch.bfloat16 else (lambda x: x.half().float())
+    q, k, v = (rnd(x) for x in (q, k, v))
+    dq, dk, dv = (t.to(dtype).cuda() for t in (q, k, v))
+    for inject in (False, True):
+        refs = attn_ref(q, k, v, h, d ** -0.5, inject)
+        for no_split in (True, False):
+            out = ops.ext_attn(dq, dk, dv, h, d ** -0.5, inject, fused=False, no_split=no_split, hints=_lib.TF_ATTN_HINT_MIX)
+            assert torch.isfinite(out.float()).all()
+            assert_attn_close(out, refs, f"mixed shapes K{K} S{S} h{h} {dtype} gain={gain} inject={inject} no_split={no_split}",
+                              dtype=dtype)
+    # fp32 output (the normalised accumulator): both forms within north_star's 1e-3 of the oracle where the streaming kernels are
+    # what the library takes (frames of <= 256 tokens run in the fused kernel with P as hi + lo: the 16-bit P of a streaming
+    # kernel averages too few keys there, 1.2e-3 at S = 256 for either form)
+    if gain == 0.0 and S >= 576:
+        refs = attn_ref(q, k, v, h, d ** -0.5, False)
+        for hints in (0, _lib.TF_ATTN_HINT_MIX):
+            o32 = ops.ext_attn(dq, dk, dv, h, d ** -0.5, False, fused=False, out_dtype=torch.float32, hints=hints)
+            assert float((o32.cpu() - refs[0]).abs().max()) < 1e-3
+
+
 @pytest.mark.parametrize("gain", [3.0, 12.0])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("d", [40, 80])

@@ -12,6 +12,7 @@ TF_ATTN_OUT_F32 = 32
 TF_ATTN_FOLD_SCALE = 64
 TF_ATTN_NO_FUSED, TF_ATTN_FUSED = 128, 1 << 17
 TF_ATTN_HINT_QB2, TF_ATTN_PRECISE_P, TF_ATTN_NO_PRECISE_P = 1 << 14, 1 << 15, 1 << 16
+TF_ATTN_HINT_MIX = 1 << 18   # Dh = 40 streaming kernel: the mixed-MFMA-shape form whatever the launch size
 
 
 def attn_hint(qw: int = 0, kw: int = 0, qb: int = 1) -> int:

@@ -89,6 +89,8 @@ struct AttnParams {
     int part;  // 0 = all three branches, TF_ATTN_BANK_ONLY, TF_ATTN_SOURCE_ONLY
     int out_f32;       // TF_ATTN_OUT_F32: `out` is float (the normalised fp32 accumulator, no 16-bit rounding)
     int nseg;          // > 1: every bank problem is split into nseg runs of bank frames (small grids, see split_plan)
+    int bit_stable;    // TF_ATTN_NO_SPLIT: kernel choice and arithmetic are functions of the shape alone
+    int mix;           // TF_ATTN_HINT_MIX: the mixed-MFMA-shape form (Dh = 40) whatever the launch size
     float* partials;   // [2 banks][Kq][H][S][nseg][Dh + 8] fp32: unnormalised O, l, log2-domain shift  // K bank frames; queries = frames q_frame0 .. +Kq
     int64_t ld;      // token stride of k and v
     int64_t ld_q;    // token stride of q (its own: a rank's q may be a column slab of the fused projection while the
@@ -1333,11 +1335,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     // ext_attn_kernel's PACK form, so the only differences to the single-bank kernel are the number of staged V^T rows
     // (VR), the number of P.V M-tiles (MT) and the epilogue's row -> (bank, feature) decode.
     constexpr bool PACK = MODE == MODE_DUAL;
-#ifndef TF_TUNE_NO_IL40_MIX
-    constexpr bool MIX = DH == 40 && !PACK && DMA == 2;   // mixed MFMA shapes, see IlScheduleMix
-#else
-    constexpr bool MIX = false;
-#endif
+    constexpr bool MIX = DMA == 3;   // DMA = 3: the DMA = 2 staging + mixed MFMA shapes, see IlScheduleMix
+    static_assert(!MIX || (DH == 40 && !PACK), "mixed MFMA shapes: Dh = 40, one bank");
 #ifdef TF_TUNE_IL40_MIX_SWZ
     constexpr bool MIXSWZ = MIX;   // slot swizzle of the mixed form's V^T image: conflict-free and 1 % SLOWER, see dv_goff below
 #else
@@ -2135,9 +2134,26 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
 #ifndef TF_TUNE_IL40_MINW
 #define TF_TUNE_IL40_MINW 4
 #endif
+            // Round 6, last session: mixed MFMA shapes (DMA = 3: QK^T 32x32x16, P.V 16x16x32 over 16-row M-tiles, see IlScheduleMix) --
+            // level-0 launch 3.57 -> 3.43 ms, cfg2 step 25.04 -> 24.48 ms on one box (profiles/r06_attn_d40_mix_ab.txt).  Its softmax is
+            // placed by hipcc, in coarser alternation with the MFMAs than the pinned steps: launches of ONE round of workgroups, whose
+            // waves run in lockstep, lose with it (a rank of 8, level 0: 3.96-4.01 against 3.88-3.89 ms per rank step, section 9 of the
+            // same file) -> only launches of >= 2 rounds (1024 eight-wave workgroups), and never in the bit-stable mode, whose kernel
+            // choice must be a function of the shape alone (a rank and the single GPU must agree bit for bit there).
+#ifndef TF_TUNE_IL40_MIX_MIN_WGS
+#define TF_TUNE_IL40_MIX_MIN_WGS 1024
+#endif
+#ifndef TF_TUNE_NO_IL40_MIX
+            const int64_t per_branch = (int64_t)p.Kq * ((p.S + 255) / 256) * p.H;
+            const bool mix_all = p.mix || (!p.bit_stable && per_branch * (2 * p.nseg + (bank_only ? 0 : 1)) >= TF_TUNE_IL40_MIX_MIN_WGS);
+            const bool mix_src = p.mix || (!p.bit_stable && per_branch >= TF_TUNE_IL40_MIX_MIN_WGS);
+#else
+            const bool mix_all = false, mix_src = false;
+#endif
 #if TF_TUNE_IL40_DMA != 0
             if (il)
-                return compose([&] { return launch_il<T, 40, TF_TUNE_IL40_NW, MODE_ALL, TF_TUNE_IL40_MINW, TF_TUNE_IL40_DMA>(p, st); },
+                return compose([&] { return mix_all ? launch_il<T, 40, TF_TUNE_IL40_NW, MODE_ALL, TF_TUNE_IL40_MINW, 3>(p, st)
+                                                    : launch_il<T, 40, TF_TUNE_IL40_NW, MODE_ALL, TF_TUNE_IL40_MINW, TF_TUNE_IL40_DMA>(p, st); },
                                [&] {
 #ifndef TF_TUNE_NO_IL40_DUAL
                                    // Round 6: the packed dual-V kernel with LDS-DMA staging, 8-wave workgroups, FOUR waves per SIMD (128
@@ -2157,7 +2173,8 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
 #endif
                                    return launch_one<T, DH, 1, 4, MODE_DUAL, 3, false>(p, st);
                                },
-                               [&] { return launch_il<T, 40, 8, MODE_SOURCE, 4, TF_TUNE_IL40_DMA>(p, st); });
+                               [&] { return mix_src ? launch_il<T, 40, 8, MODE_SOURCE, 4, 3>(p, st)
+                                                    : launch_il<T, 40, 8, MODE_SOURCE, 4, TF_TUNE_IL40_DMA>(p, st); });
 #endif
             return compose([&] {
 #ifdef TF_TUNE_IL40_NW4_SMALL
@@ -2366,6 +2383,8 @@ extern "C" int tf_ext_attn_fwd_strided(const void* q, const void* k, const void*
     p.fold = (inject & TF_ATTN_FOLD_SCALE) ? 1 : 0;
     p.out_f32 = (inject & TF_ATTN_OUT_F32) ? 1 : 0;
     p.nseg = split_plan(K, Kq, S, H, Dh, p.inject != 0, p.part, !(inject & TF_ATTN_NO_SPLIT));
+    p.bit_stable = (inject & TF_ATTN_NO_SPLIT) ? 1 : 0;
+    p.mix = (inject & TF_ATTN_HINT_MIX) ? 1 : 0;
     p.partials = reinterpret_cast<float*>(
         reinterpret_cast<unsigned char*>(const_cast<float*>(p.knorm2)) +
         (((size_t)3 * H * K * (((S + 127) / 128) * 128 / 64) * sizeof(float) + 255) & ~(size_t)255));

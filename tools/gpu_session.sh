@@ -151,6 +151,8 @@ for stage in "$@"; do
                   TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 8,4096,8,40 4,1024,8,40 2>/dev/null | grep "inject=0" | tee -a $O/attn_d40_mix_ab6.txt; done
                 rm -rf /tmp/sq; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES -d /tmp/sq -- python $GRAFT_REPO_ROOT/tools/attn_microbench.py 8,4096,8,40 > /dev/null 2>&1 )
                 python tools/rocpd_pmc.py $(find /tmp/sq -name "*_results.db" | head -1) | grep "il_kernel<BF16; 40; 8; 0" | tee -a $O/attn_d40_mix_ab6.txt ;;
+    mixrank)    for lib in nomix "" nomix ""; do echo "== lib=${lib:-default}" | tee -a $O/rank_step_mix_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 600 python tools/rank_step_microbench.py --native --only split,auto --no-copies --reps 12 2>/dev/null | grep "step inject\|level 0" | tee -a $O/rank_step_mix_ab.txt; done ;;
     fusedbench) timeout 600 python tools/fused_microbench.py > $O/fused_microbench.txt 2>&1; tail -40 $O/fused_microbench.txt ;;
     rankstep)   timeout 600 python tools/rank_step_microbench.py --native --only split,auto > $O/rank_step_native.txt 2>&1; tail -14 $O/rank_step_native.txt
                 timeout 300 python tools/rank_step_microbench.py --native --only split,auto --no-copies --no-levels > $O/rank_step_native_nocopies.txt 2>&1; tail -3 $O/rank_step_native_nocopies.txt
