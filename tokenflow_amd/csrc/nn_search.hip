@@ -759,6 +759,165 @@ __global__ __launch_bounds__(256, TT == 1 ? 3 : 2) void nn_search_rbg_kernel(con
     }
 }
 
+// ---------------------------------------------------------------------------
+// The two-target-tile kernel above with SHORT MFMAs (round 6, last session): v_mfma_f32_16x16x32 instead of 32x32x16.  Same
+// workgroup (4 waves x 64 targets), same LDS image of a pivot tile (32 x D, dense, DMA-staged, pieces XOR-swizzled with
+// (row >> 1) & 7 -- conflict-free for this read pattern too), same bytes through the LDS per flop, same matrix-pipe clocks:
+// a wave's 64 targets are four 16-target B-fragment sets (160 VGPRs), a pivot tile two 16-row A fragments per 32-wide k-step,
+// each feeding four MFMAs.  Why: on these power-limited boxes the short shape sustains ~16 % more in an MFMA-bound loop
+// (tools/ubench/nn_loop_proxy.hip: 1 810 against 1 555 TF/s in the stripped loop of this kernel; the bare MFMAs 2 213 against
+// 1 894, profiles/r02_mfma_shapes.txt) -- less accumulator traffic per flop.
+// TJ = 16-target sub-tiles per wave: 4 (the two-target-tile form: 256 targets per workgroup) or 2 (the one-tile form: 128).
+// Arithmetic: a (target, pivot) dot product is summed 32 features per MFMA in ascending order -- NOT bit-identical to the
+// 16-wide steps of the other search kernels (fp32 rounding of the partial sums); exact duplicates still tie exactly (the same
+// instruction sequence on the same data) and the first index wins as everywhere (ascending rows, strict '>').
+template <typename T, int DK, int TJ = 4>
+__global__ __launch_bounds__(256, TJ == 4 ? 2 : 3) void nn_search_rbs_kernel(const typename T::elem* __restrict__ tgt,
+                                                               const typename T::elem* __restrict__ piv,
+                                                               const float* __restrict__ inv_norm,
+                                                               int32_t* __restrict__ idx_out,
+                                                               NnPartial* __restrict__ part_out, int64_t n_tgt, int S,
+                                                               int kf0, int kf1, int tiles_per_split, NnChunks ch) {
+    typedef typename T::elem E;
+    typedef typename T::vec8 vec8;
+    constexpr int D = 16 * DK;
+    constexpr int KS32 = D / 32;             // 32-wide k-steps
+    static_assert(D % 32 == 0 && (D / 8) % 8 == 0, "32-wide k-steps; the swizzle permutes inside groups of 8 pieces");
+    constexpr int TMR = 32;                  // pivots per tile
+    constexpr int NPIECE = TMR * D * 2 / 1024;
+    static_assert(NPIECE % 4 == 0, "pieces split evenly over the 4 waves");
+    constexpr int A_ELEMS = TMR * D;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    auto sA = [&](int b) { return reinterpret_cast<E*>(smem) + b * A_ELEMS; };
+    float* sInv = reinterpret_cast<float*>(smem + 2 * A_ELEMS * sizeof(E));  // [2][TMR]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int g = lane >> 4;      // 16-lane row: the k-block of the A / B fragments, the row group of C
+    const int n16 = lane & 15;    // A: pivot row of the 16-row sub-tile; B / C: target of the 16-target sub-tile
+    const int p = blockIdx.y;
+    const int chunk = blockIdx.x / ch.ppc;       // see nn_search_kernel
+    if (p == 1 && chunk == 0 && ch.first_single) return;
+    const int kf = (p == 0 ? kf0 : kf1) + chunk;
+    const E* pv = piv + (int64_t)kf * S * D;
+    const float* inv = inv_norm + (int64_t)kf * S;
+    const int64_t t_end = (chunk + 1) * ch.nS;
+    int64_t t_row[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+        t_row[j] = chunk * ch.nS + (int64_t)(blockIdx.x - chunk * ch.ppc) * (64 * TJ) + wave * (16 * TJ) + 16 * j + n16;
+
+    const int n_mt_all = (S + TMR - 1) / TMR;
+    const int mt0 = blockIdx.z * tiles_per_split;
+    const int n_mt = min(tiles_per_split, n_mt_all - mt0);
+
+    vec8 fb[TJ][KS32];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const E* tp = tgt + (t_row[j] < t_end ? t_row[j] : t_end - 1) * D + 8 * g;
+#pragma unroll
+        for (int t = 0; t < KS32; ++t) fb[j][t] = __builtin_bit_cast(vec8, ld16(tp + 32 * t));
+    }
+
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int a_off[NPIECE / 4];
+#pragma unroll
+    for (int i = 0; i < NPIECE / 4; ++i) {
+        const int o = (wave_u + 4 * i) * 1024 + lane * 16;
+        const int r = o / (2 * D), pos = (o - r * 2 * D) >> 4;
+        a_off[i] = r * D + ((pos ^ ((r >> 1) & 7)) << 3);
+    }
+    float rinv = 0.f;
+    auto stage_load = [&](int mt) {
+        unsigned char* a = reinterpret_cast<unsigned char*>(sA(mt & 1));
+        const E* tile = pv + (int64_t)(mt0 + mt) * TMR * D;
+#pragma unroll
+        for (int i = 0; i < NPIECE / 4; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(tile + a_off[i]), (lds_ptr)(a + (wave_u + 4 * i) * 1024), 16, 0, 0);
+        if (tid < TMR) {
+            int row = (mt0 + mt) * TMR + tid;
+            rinv = inv[row < S ? row : S - 1];
+        }
+    };
+    auto stage_write = [&](int mt) {
+        if (tid < TMR) sInv[(mt & 1) * TMR + tid] = rinv;
+    };
+
+    float best_v[TJ];
+    int best_i[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) best_v[j] = -INFINITY, best_i[j] = 0;
+    stage_load(0);
+    stage_write(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int mt = 0; mt < n_mt; ++mt) {
+        const bool has_next = mt + 1 < n_mt;
+        if (has_next) stage_load(mt + 1);
+        f32x4 acc[2][TJ];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const E* a0 = sA(mt & 1);
+#pragma unroll
+        for (int t = 0; t < KS32; ++t) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = 16 * i + n16;   // pivot row of the tile; its 16-B piece 4 t + g, swizzled as stored
+                const vec8 fa = __builtin_bit_cast(vec8, ld16(a0 + r * D + (((4 * t + g) ^ ((r >> 1) & 7)) << 3)));
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = T::mfma16(fa, fb[j][t], acc[i][j]);
+            }
+        }
+        const float* si = sInv + (mt & 1) * TMR;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rl = 16 * i + 4 * g + r;   // ascending within the lane: first index wins with the strict '>'
+                const float w = si[rl];
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const float sc = acc[i][j][r] * w;
+                    if (sc > best_v[j]) {
+                        best_v[j] = sc;
+                        best_i[j] = (mt0 + mt) * TMR + rl;
+                    }
+                }
+            }
+        if (has_next) stage_write(mt + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // the four 16-lane rows hold disjoint pivot rows of the same target: merge, lower index on equal scores
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        float bv = best_v[j];
+        int bi = best_i[j];
+#pragma unroll
+        for (int o_ = 16; o_ <= 32; o_ <<= 1) {
+            const float ov = __shfl_xor(bv, o_);
+            const int oi = __shfl_xor(bi, o_);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        bi = bi < S ? bi : S - 1;
+        if (g == 0 && t_row[j] < t_end) {
+            if (part_out)
+                part_out[((int64_t)blockIdx.z * gridDim.y + p) * n_tgt + t_row[j]] = NnPartial{bv, bi};
+            else
+                idx_out[(int64_t)p * n_tgt + t_row[j]] = bi;
+        }
+    }
+}
+
 // merge the per-split candidates: ascending split order == ascending pivot index
 __global__ __launch_bounds__(256) void nn_finalize_kernel(const NnPartial* __restrict__ part,
                                                           int32_t* __restrict__ idx_out, int64_t total, int splits) {
@@ -933,6 +1092,14 @@ int launch_nn_rb(const void* tgt, const void* piv, const float* inv_norm, int32_
     const NnChunks ch{n_tgt, (int)pl.panels, first_single};
     if (pl.kern == NN_RB2) {   // 256-target panels, two target tiles per wave (the plan has checked S % 32 == 0)
         const size_t lds_g = 2 * 32 * D * 2 + 2 * 32 * 4;
+#ifndef TF_TUNE_NN_NO_RBS
+        // round 6, last session: the same kernel with short MFMAs (16x16x32), see nn_search_rbs_kernel
+        hipLaunchKernelGGL((nn_search_rbs_kernel<T, DK>), grid, dim3(256), lds_g, st,
+                           reinterpret_cast<const typename T::elem*>(tgt), reinterpret_cast<const typename T::elem*>(piv),
+                           inv_norm, idx, (splits > 1 || !fin) ? ws : nullptr, n_tgt * C, S, kf0, kf1, tps, ch);
+        TF_LAUNCH_CHECK("tf_nn_search");
+        return (fin && splits > 1) ? finalize(ws, idx, n_tgt * C * P, splits, st) : 0;
+#endif
         hipLaunchKernelGGL((nn_search_rbg_kernel<T, DK, 2>), grid, dim3(256), lds_g, st,
                            reinterpret_cast<const typename T::elem*>(tgt), reinterpret_cast<const typename T::elem*>(piv),
                            inv_norm, idx, (splits > 1 || !fin) ? ws : nullptr, n_tgt * C, S, kf0, kf1, tps, ch);
@@ -944,6 +1111,13 @@ int launch_nn_rb(const void* tgt, const void* piv, const float* inv_norm, int32_
     static const bool dma = [] { const char* e = getenv("TF_NN_RB_GLDS"); return !e || atoi(e) != 0; }();
     if (dma && S % 32 == 0) {
         const size_t lds_g = 2 * 32 * D * 2 + 2 * 32 * 4;
+#ifndef TF_TUNE_NN_NO_RBS
+        hipLaunchKernelGGL((nn_search_rbs_kernel<T, DK, 2>), grid, dim3(256), lds_g, st,
+                           reinterpret_cast<const typename T::elem*>(tgt), reinterpret_cast<const typename T::elem*>(piv),
+                           inv_norm, idx, (splits > 1 || !fin) ? ws : nullptr, n_tgt * C, S, kf0, kf1, tps, ch);
+        TF_LAUNCH_CHECK("tf_nn_search");
+        return (fin && splits > 1) ? finalize(ws, idx, n_tgt * C * P, splits, st) : 0;
+#endif
         hipLaunchKernelGGL((nn_search_rbg_kernel<T, DK>), grid, dim3(256), lds_g, st,
                            reinterpret_cast<const typename T::elem*>(tgt), reinterpret_cast<const typename T::elem*>(piv),
                            inv_norm, idx, (splits > 1 || !fin) ? ws : nullptr, n_tgt * C, S, kf0, kf1, tps, ch);

@@ -153,6 +153,11 @@ for stage in "$@"; do
                 python tools/rocpd_pmc.py $(find /tmp/sq -name "*_results.db" | head -1) | grep "il_kernel<BF16; 40; 8; 0" | tee -a $O/attn_d40_mix_ab6.txt ;;
     mixrank)    for lib in nomix "" nomix ""; do echo "== lib=${lib:-default}" | tee -a $O/rank_step_mix_ab.txt
                   TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 600 python tools/rank_step_microbench.py --native --only split,auto --no-copies --reps 12 2>/dev/null | grep "step inject\|level 0" | tee -a $O/rank_step_mix_ab.txt; done ;;
+    rbsab)      # round 6: the two-target-tile search with short MFMAs (nn_search_rbs_kernel, 16x16x32) against the 32x32x16 form (lib_norbs.so)
+                timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_fullsize_gpu.py tests/test_baseline_configs_gpu.py -q --tb=short -p no:cacheprovider -k "nn_search or propagat or iid or two_tile or cfg2 or cfg4" 2>&1 | tail -8 | tee -a $O/nn_rbs_ab.txt
+                for lib in norbs "" norbs "" norbs ""; do echo "== lib=${lib:-default}" | tee -a $O/nn_rbs_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/prop_microbench.py 8,5,4096,320 10,8,9216,320 25,8,4096,320 2>/dev/null | grep "one call" | tee -a $O/nn_rbs_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/nn_microbench.py 8,5,4096,320 2>/dev/null | tee -a $O/nn_rbs_ab.txt; done ;;
     fusedbench) timeout 600 python tools/fused_microbench.py > $O/fused_microbench.txt 2>&1; tail -40 $O/fused_microbench.txt ;;
     rankstep)   timeout 600 python tools/rank_step_microbench.py --native --only split,auto > $O/rank_step_native.txt 2>&1; tail -14 $O/rank_step_native.txt
                 timeout 300 python tools/rank_step_microbench.py --native --only split,auto --no-copies --no-levels > $O/rank_step_native_nocopies.txt 2>&1; tail -3 $O/rank_step_native_nocopies.txt
