@@ -1281,15 +1281,15 @@ struct IlSchedule {   // MFMA order of one phase: QK^T k-steps (one accumulator 
 // THREE 16-row M-tiles (rows 0-47 of the same V^T image: 40 features, the ones row, 7 zero rows) and the two 16-query halves
 // of the wave's tile: 6 short MFMAs (16 clocks each) per 32-key half instead of 4 long ones -- 192 instead of 224 matrix-pipe
 // clocks per phase.  A step's fragment is read once per M-tile (fidx: the step whose LDS fragment this step multiplies).
-template <int KS, bool NEXT>
-struct IlScheduleMix {
-    static constexpr int N = (NEXT ? KS : 0) + 6;
+template <int NT, int KS, bool NEXT>
+struct IlScheduleMix {   // NT = 16-row M-tiles of P.V (3 at Dh = 40: 48 rows; 4 at Dh = 64)
+    static constexpr int N = (NEXT ? KS : 0) + 2 * NT;
     int is_pv[N] = {}, a[N] = {}, b[N] = {}, fidx[N] = {};   // P.V: a = M-tile, b = 16-query half; QK^T: a = k-step
     constexpr IlScheduleMix() {
         int i = 0;
         if (NEXT) {
-            // QK0 PV00 PV01 | QK1 PV10 PV11 | QK2 PV20 PV21: the QK^T chain's links lie two short MFMAs (32 clocks) apart
-            for (int d = 0; d < 3; ++d) {
+            // QK0 PV00 PV01 | QK1 PV10 PV11 | QK2 PV20 PV21 ...: the QK^T chain's links lie two short MFMAs (32 clocks) apart
+            for (int d = 0; d < NT; ++d) {
                 if (d < KS) {
                     is_pv[i] = 0, a[i] = d, fidx[i] = i;
                     ++i;
@@ -1298,14 +1298,19 @@ struct IlScheduleMix {
                 is_pv[i + 1] = 1, a[i + 1] = d, b[i + 1] = 1, fidx[i + 1] = i;
                 i += 2;
             }
-            for (int t = 3; t < KS; ++t) {
+            for (int t = NT; t < KS; ++t) {
                 is_pv[i] = 0, a[i] = t, fidx[i] = i;
                 ++i;
             }
         } else {
-            // PV00 PV10 PV01 PV11 PV20 PV21: the first two steps own their fragments (cross-phase prefetch hands over two)
-            const int dd[6] = {0, 1, 0, 1, 2, 2}, tt[6] = {0, 0, 1, 1, 0, 1}, ff[6] = {0, 1, 0, 1, 4, 4};
-            for (i = 0; i < 6; ++i) is_pv[i] = 1, a[i] = dd[i], b[i] = tt[i], fidx[i] = ff[i];
+            // PV00 PV10 PV01 PV11 | PV20 PV21 | PV30 PV31: the first two steps own their fragments (cross-phase prefetch hands over two)
+            const int dd[4] = {0, 1, 0, 1}, tt[4] = {0, 0, 1, 1}, ff[4] = {0, 1, 0, 1};
+            for (i = 0; i < 4; ++i) is_pv[i] = 1, a[i] = dd[i], b[i] = tt[i], fidx[i] = ff[i];
+            for (int d = 2; d < NT; ++d) {
+                is_pv[i] = 1, a[i] = d, b[i] = 0, fidx[i] = i;
+                is_pv[i + 1] = 1, a[i + 1] = d, b[i + 1] = 1, fidx[i + 1] = i;
+                i += 2;
+            }
         }
     }
 };
@@ -1336,7 +1341,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     // (VR), the number of P.V M-tiles (MT) and the epilogue's row -> (bank, feature) decode.
     constexpr bool PACK = MODE == MODE_DUAL;
     constexpr bool MIX = DMA == 3;   // DMA = 3: the DMA = 2 staging + mixed MFMA shapes, see IlScheduleMix
-    static_assert(!MIX || (DH == 40 && !PACK), "mixed MFMA shapes: Dh = 40, one bank");
+    static_assert(!MIX || ((DH == 40 || DH == 64) && !PACK), "mixed MFMA shapes: Dh = 40 or 64, one bank");
+    constexpr int NT16 = DH == 40 ? 3 : (DH + 15) / 16;   // MIX: 16-row M-tiles of P.V (Dh = 40: features + the ones row + 7 zero rows)
 #ifdef TF_TUNE_IL40_MIX_SWZ
     constexpr bool MIXSWZ = MIX;   // slot swizzle of the mixed form's V^T image: conflict-free and 1 % SLOWER, see dv_goff below
 #else
@@ -1566,7 +1572,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
     f32x16 o[MT], s[2];
-    f32x4 o16[3][2];    // MIX: O^T as [16-row M-tile][16-query half]: lane l = query l & 15 of the half, rows 4 (l >> 4) + i
+    f32x4 o16[NT16][2]; // MIX: O^T as [16-row M-tile][16-query half]: lane l = query l & 15 of the half, rows 4 (l >> 4) + i
     vec8 pf[2][2];      // P of the two 32-key halves, two 16-key k-steps each (MIX: after p_relayout, the two 16-query halves)
     float m_run = -INFINITY;   // BOUND: deferred shift; else the lagged running maximum (raw-score units)
     const float lag = TF_ATTN_LAG / c;   // raw-score units
@@ -1590,7 +1596,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[mt][r] = 0.f;
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
+    for (int d = 0; d < NT16; ++d)
 #pragma unroll
         for (int t = 0; t < 2; ++t) o16[d][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1662,7 +1668,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
             const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(alpha), __float_as_uint(alpha), false, false);
             const float a0 = __uint_as_float(r[0]), a1 = __uint_as_float(r[1]);
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
+            for (int d = 0; d < NT16; ++d) {
                 o16[d][0] *= a0;
                 o16[d][1] *= a1;
             }
@@ -1715,7 +1721,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
     auto frag = [&](auto h_c, auto next_c, int i, int vbuf, int kbuf) -> vec8 {
         constexpr int Hh = decltype(h_c)::value;
         if constexpr (MIX) {
-            constexpr IlScheduleMix<C::KS, decltype(next_c)::value> schm{};
+            constexpr IlScheduleMix<NT16, C::KS, decltype(next_c)::value> schm{};
             if (schm.is_pv[i])   // 16 rows x 32 keys of M-tile a: lane row g reads the image columns of k-step g & 1, lane half g >> 1
                 return __builtin_bit_cast(vec8, ld16(sV(vbuf) + (schm.a[i] * 16 + (lane & 15)) * VROW + Hh * 32 +
                                                      16 * (((lane >> 4) ^ (MIXSWZ ? (lane + 4) >> 3 : 0)) & 1) + 8 * hi));   // rows 4-11: slot bit 1 flipped
@@ -1745,7 +1751,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
         constexpr bool NEXT = decltype(next_c)::value, SM = decltype(sm_c)::value;
         constexpr bool PRE_IN = XPF && decltype(pre_in_c)::value;     // fragments 0 .. PF-1 arrive in fr_carry
         constexpr bool PRE_OUT = XPF && decltype(pre_out_c)::value;   // the following phase (half 1 - Hh, same NEXT, same buffers) gets its first PF
-        constexpr std::conditional_t<MIX, IlScheduleMix<C::KS, NEXT>, IlSchedule<MT, C::KS, NEXT>> sch{};
+        constexpr std::conditional_t<MIX, IlScheduleMix<NT16, C::KS, NEXT>, IlSchedule<MT, C::KS, NEXT>> sch{};
         constexpr int NM = sch.N;
         static_assert(PF <= NM, "prefetch distance beyond one phase");
         bool move = false;
@@ -1806,12 +1812,12 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
             // P of half X must exist HERE (keeps the register-only softmax from sinking towards its consumer)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(pf[X][ks]));
-            if constexpr (MIX) {
+            if constexpr (LSUM_MFMA) lacc = T::mfma4(ones4, pf[X][1].hi, lacc);   // the last pair of the half (units 6, 7)
+            if constexpr (MIX) {   // (behind the denominator's last pair: it sums the lane's OWN P values)
                 p_relayout(std::integral_constant<int, X>{});
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(pf[X][ks]));
             }
-            if constexpr (LSUM_MFMA) lacc = T::mfma4(ones4, pf[X][1].hi, lacc);   // the last pair of the half (units 6, 7)
             // the shift moved: O (now including this phase's P.V, computed against the old shift) -- and the part of
             // the denominator accumulated so far, all of it at the old shift -- is rescaled before any P at the new
             // shift is multiplied in / added
@@ -1856,8 +1862,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
         float lsum = 0.f;
 #pragma unroll
         for (int un = 0; un < 8; ++un) sm_unit(H0{}, un, c2, mc2, lsum);
-        if constexpr (MIX) p_relayout(H0{});
         if constexpr (LSUM_MFMA) lacc = T::mfma4(ones4, pf[0][1].hi, lacc);
+        if constexpr (MIX) p_relayout(H0{});
         if constexpr (!ONES && !LSUM_MFMA) l_run = lsum;
     }
 
@@ -1918,8 +1924,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
         // M-tile 2 in the lanes of row g = 2
         const int g = lane >> 4, n16 = lane & 15;
         float l_t[2];
+        if constexpr (ONES) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) l_t[t] = __shfl(o16[2][t][0], 32 + n16);
+            for (int t = 0; t < 2; ++t) l_t[t] = __shfl(o16[2][t][0], 32 + n16);
+        } else {   // Dh = 64: the matrix-pipe denominator of query l & 31 (both lane halves hold a part)
+            const float lq = LSUM_MFMA ? lacc[0] + __shfl_xor(lacc[0], 32) : l_run + __shfl_xor(l_run, 32);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) l_t[t] = __shfl(lq, 16 * t + n16);
+        }
         if (split) {
             constexpr int PS = DH + 8;
 #pragma unroll
@@ -1929,9 +1941,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
                     const int64_t R = (((int64_t)(b - 1) * Kq + f) * H + h) * S + qr;
                     float* row = p.partials + (R * nseg + seg) * PS;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d)
+                    for (int d = 0; d < NT16; ++d)
                         if (16 * d + 4 * g < DH) *reinterpret_cast<f32x4*>(row + 16 * d + 4 * g) = o16[d][t];
-                    if (g == 2) row[DH] = o16[2][t][0];
+                    if (g == 0) row[DH] = l_t[t];
                 }
             }
             if (hi == 0 && q_ok) {   // the shift is this lane's own query's (l & 31)
@@ -1946,7 +1958,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ext_attn_il_kernel(AttnParams p
                     const float inv = 1.0f / l_t[t];
                     const int64_t op = b * p.o_bs + f * p.o_fs + (int64_t)qr * (H * DH) + h * DH;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d)
+                    for (int d = 0; d < NT16; ++d)
                         if (16 * d + 4 * g < DH) store_out4<E, vec4>(p.out, op + 16 * d + 4 * g, o16[d][t] * inv, p.out_f32);
                 }
             }
@@ -2231,7 +2243,17 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
 #else
         const bool il = false;
 #endif
-        return compose([&] { return il ? launch_il<T, DH, TF_TUNE_IL64_NW, MODE_ALL, TF_TUNE_IL64_MINW, TF_TUNE_IL64_DMA>(p, st)
+#ifdef TF_TUNE_IL64_MIX
+        // A/B switch: the mixed MFMA shapes at Dh = 64 (P.V as 16x16x32 over four 16-row M-tiles: the same matrix-pipe clocks, no
+        // padding to remove here; the question is the short shape's power efficiency), launches of >= 1024 workgroups
+        const int64_t per_branch64 = (int64_t)p.Kq * ((p.S + 255) / 256) * p.H;
+        const bool mix64 = il && (p.mix || (!p.bit_stable && per_branch64 * (2 * p.nseg + (bank_only ? 0 : 1)) >= 1024));
+        const bool mix64s = il && (p.mix || (!p.bit_stable && per_branch64 >= 1024));
+#else
+        const bool mix64 = false, mix64s = false;
+#endif
+        return compose([&] { return mix64 ? launch_il<T, DH, TF_TUNE_IL64_NW, MODE_ALL, TF_TUNE_IL64_MINW, 3>(p, st)
+                                  : il ? launch_il<T, DH, TF_TUNE_IL64_NW, MODE_ALL, TF_TUNE_IL64_MINW, TF_TUNE_IL64_DMA>(p, st)
                                   : (p.S >= 512 && p.nseg == 1) ? launch_pp<T, DH, MODE_ALL, 2>(p, st)   // ragged frames: ping-pong
                                                                 : launch_one<T, DH, 1, 4, MODE_ALL, 2>(p, st); },
                        [&] {
@@ -2246,7 +2268,8 @@ int launch_attn(const AttnParams& p, const void* v, hipStream_t st) {
                                 if (il) return launch_il<T, DH, TF_TUNE_IL64_DUAL_NW, MODE_DUAL, 2, 2>(p, st);
 #endif
                                 return launch_one<T, DH, 1, 4, MODE_DUAL, 2>(p, st); },
-                       [&] { return il ? launch_il<T, DH, TF_TUNE_IL64_NW, MODE_SOURCE, TF_TUNE_IL64_MINW, TF_TUNE_IL64_DMA>(p, st)
+                       [&] { return mix64s ? launch_il<T, DH, TF_TUNE_IL64_NW, MODE_SOURCE, TF_TUNE_IL64_MINW, 3>(p, st)
+                                    : il ? launch_il<T, DH, TF_TUNE_IL64_NW, MODE_SOURCE, TF_TUNE_IL64_MINW, TF_TUNE_IL64_DMA>(p, st)
                                        : launch_one<T, DH, 1, 4, MODE_SOURCE, 2>(p, st); });
     } else if constexpr (DH == 80) {
         // Round 6: LDS-DMA staging (padded images) frees the staging registers: 146 VGPRs with 4-wave workgroups, THREE of which
