@@ -287,7 +287,10 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const typename T::elem* 
 // involution (swz_off<64>).  Two LDS buffers; the DMA of chunk it+1 is issued before the MFMAs of chunk it and
 // drained (vmcnt(0)) in front of the interval's barrier.  The pivots' inverse norms of a tile arrive the same way.
 // Arithmetic per (target, pivot) and the first-index rule are those of nn_search_kernel.
-template <typename T>
+// SH (round 6, last session): the wave's 64 x 128 tile as 4 x 8 sub-tiles of v_mfma_f32_16x16x32 instead of 2 x 4 of 32x32x16 -- same
+// images, same bytes through the LDS, same matrix-pipe clocks and accumulator registers; the short shape sustains more on these
+// power-limited boxes (see nn_search_rbs_kernel).  32 features per MFMA: scores differ from the SH = false kernel's in the last bit.
+template <typename T, bool SH = false>
 __global__ __launch_bounds__(512, 2) void nn_search_glds_kernel(const typename T::elem* __restrict__ tgt,
                                                                 const typename T::elem* __restrict__ piv,
                                                                 const float* __restrict__ inv_norm,
@@ -315,6 +318,8 @@ __global__ __launch_bounds__(512, 2) void nn_search_glds_kernel(const typename T
     const int wc = wave & 1;    // target half   (cols wc*128 .. +127)
     const int hi = lane >> 5;
     const int l31 = lane & 31;
+    const int g = lane >> 4, n16 = lane & 15;   // SH: 16-lane row (k-block of A / B, row group of C), row / column in a sub-tile
+    constexpr int NB = SH ? 2 * WN : WN;        // running (max, argmax) pairs per lane: one per target sub-tile
 
     const int p = blockIdx.y;
     const int chunk = blockIdx.x / ch.ppc;
@@ -378,10 +383,11 @@ __global__ __launch_bounds__(512, 2) void nn_search_glds_kernel(const typename T
     };
 
     f32x16 acc[NI][WN];
-    float best_v[WN];
-    int best_i[WN];
+    f32x4 acc16[2 * NI][2 * WN];   // SH
+    float best_v[NB];
+    int best_i[NB];
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
+    for (int j = 0; j < NB; ++j) {
         best_v[j] = -INFINITY;
         best_i[j] = 0;
     }
@@ -402,9 +408,29 @@ __global__ __launch_bounds__(512, 2) void nn_search_glds_kernel(const typename T
                 for (int j = 0; j < WN; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2 * NI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2 * WN; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         const unsigned char* a = sA(it & 1);
         const unsigned char* b = sB(it & 1);
+        if constexpr (SH) {
+#pragma unroll
+            for (int ks = 0; ks < BK / 32; ++ks) {
+                vec8 fa[2 * NI], fb[2 * WN];
+#pragma unroll
+                for (int i = 0; i < 2 * NI; ++i)
+                    fa[i] = __builtin_bit_cast(vec8, ld16(a + swz_off<BK>(wr * 64 + i * 16 + n16, ks * 4 + g)));
+#pragma unroll
+                for (int j = 0; j < 2 * WN; ++j)
+                    fb[j] = __builtin_bit_cast(vec8, ld16(b + swz_off<BK>((wc * 2 * WN + j) * 16 + n16, ks * 4 + g)));
+#pragma unroll
+                for (int i = 0; i < 2 * NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2 * WN; ++j) acc16[i][j] = T::mfma16(fa[i], fb[j], acc16[i][j]);
+            }
+        } else
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             vec8 fa[NI], fb[WN];
@@ -428,6 +454,24 @@ __global__ __launch_bounds__(512, 2) void nn_search_glds_kernel(const typename T
             // argmax epilogue: rows visited in ascending order, strict '>' keeps the first maximum
             const float* si = sInv + (mt & 1) * TM;
             const int last = S - 1 - (mt0 + mt) * TM;   // rows past S are copies of row S - 1: give them ITS inverse norm
+            if constexpr (SH) {
+#pragma unroll
+                for (int i = 0; i < 2 * NI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rl = wr * 64 + i * 16 + 4 * g + r;   // ascending within the lane
+                        const float w = si[min(rl, last)];
+                        const int gi = (mt0 + mt) * TM + rl;
+#pragma unroll
+                        for (int j = 0; j < 2 * WN; ++j) {
+                            const float sc = acc16[i][j][r] * w;
+                            if (sc > best_v[j]) {
+                                best_v[j] = sc;
+                                best_i[j] = gi;
+                            }
+                        }
+                    }
+            } else
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
 #pragma unroll
@@ -450,6 +494,25 @@ __global__ __launch_bounds__(512, 2) void nn_search_glds_kernel(const typename T
         __syncthreads();
     }
 
+    if constexpr (SH) {   // the four 16-lane rows hold disjoint pivot rows of a target: merge, smaller index on equal scores
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+#pragma unroll
+            for (int o_ = 16; o_ <= 32; o_ <<= 1) {
+                const float ov = __shfl_xor(best_v[j], o_);
+                const int oi = __shfl_xor(best_i[j], o_);
+                if (ov > best_v[j] || (ov == best_v[j] && oi < best_i[j])) {
+                    best_v[j] = ov;
+                    best_i[j] = oi;
+                }
+            }
+            if (g == 0) {
+                const int col = (wc * NB + j) * 16 + n16;
+                sBestV[wr * TN + col] = best_v[j];
+                sBestI[wr * TN + col] = best_i[j];
+            }
+        }
+    } else
     // merge lane l with lane l+32 (interleaved row sets): tie -> smaller index
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
@@ -1071,7 +1134,11 @@ int launch_nn_glds(const void* tgt, const void* piv, const float* inv_norm, int3
     const NnPlan pl = nn_plan(n_tgt, S, D, P, C);
     const int splits = pl.splits, tps = pl.tiles_per_split;
     dim3 grid((unsigned)(pl.panels * C), (unsigned)P, (unsigned)splits);
-    auto kern = nn_search_glds_kernel<T>;
+#ifndef TF_TUNE_NN_NO_GLDS_SH
+    auto kern = nn_search_glds_kernel<T, true>;    // short MFMAs (round 6, last session)
+#else
+    auto kern = nn_search_glds_kernel<T, false>;
+#endif
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const NnChunks ch{n_tgt, (int)pl.panels, first_single};
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, reinterpret_cast<const typename T::elem*>(tgt),

@@ -162,6 +162,11 @@ for stage in "$@"; do
                 TOKENFLOW_HIP_LIB=build/variants/lib_mix64.so timeout 1200 python -m pytest tests/test_kernels_gpu.py tests/test_baseline_configs_gpu.py -q --tb=short -p no:cacheprovider -k "64 or cfg4 or cfg5 or mixed" 2>&1 | tail -6 | tee -a $O/attn_d64_mix_ab.txt
                 for lib in "" mix64 "" mix64; do echo "== lib=${lib:-default}" | tee -a $O/attn_d64_mix_ab.txt
                   TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/attn_microbench.py 10,9216,5,64 25,4096,5,64 10,2304,10,64 2>/dev/null | grep "inject=0" | tee -a $O/attn_d64_mix_ab.txt; done ;;
+    gldsshab)   # round 6: the LDS-DMA search kernel (D >= 512; D = 320 with <= 1024 pivots) with short MFMAs against the 32x32x16 form (lib_nogldssh.so)
+                timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_fullsize_gpu.py tests/test_baseline_configs_gpu.py -q --tb=short -p no:cacheprovider -k "nn_search or propagat or iid or lds_dma or cfg1 or cfg2 or cfg4 or cfg5" 2>&1 | tail -6 | tee -a $O/nn_glds_sh_ab.txt
+                for lib in nogldssh "" nogldssh "" nogldssh ""; do echo "== lib=${lib:-default}" | tee -a $O/nn_glds_sh_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/prop_microbench.py 8,5,1024,640 10,8,2304,640 25,8,1024,640 8,5,256,1280 4,2,1024,320 2>/dev/null | grep "one call" | tee -a $O/nn_glds_sh_ab.txt
+                  TOKENFLOW_HIP_LIB=${lib:+build/variants/lib_$lib.so} timeout 300 python tools/nn_microbench.py 8,5,1024,640 2>/dev/null | tee -a $O/nn_glds_sh_ab.txt; done ;;
     fusedbench) timeout 600 python tools/fused_microbench.py > $O/fused_microbench.txt 2>&1; tail -40 $O/fused_microbench.txt ;;
     rankstep)   timeout 600 python tools/rank_step_microbench.py --native --only split,auto > $O/rank_step_native.txt 2>&1; tail -14 $O/rank_step_native.txt
                 timeout 300 python tools/rank_step_microbench.py --native --only split,auto --no-copies --no-levels > $O/rank_step_native_nocopies.txt 2>&1; tail -3 $O/rank_step_native_nocopies.txt
